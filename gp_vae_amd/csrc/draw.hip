@@ -1,0 +1,211 @@
+// draw.hip — MVN draws from a Cholesky factor, and counter-based normals.
+//
+// gpvae_draw replaces  f = L eps ; y = f + sigma eps'  of GP.sample under Predictive
+// (/root/reference/src/model/gp.py:190-194, vae.py:160-162,223-226) for nb draws that share L:
+//   F[r][i] = sum_{j<=i} E[r][j] L[i][j]          (a triangular matrix product, n^2*nb flop)
+// as a 128x128-tiled f32/f64 MFMA product whose k loop stops at the diagonal of L; the strict upper
+// part of L is masked in the loader, so it may hold anything.  Column tiles are issued heaviest
+// first (their k range grows with the column index).  Bound: MFMA.
+#include "gemm_core.hpp"
+
+namespace gpvae {
+
+constexpr int DBM = 128;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void draw_kernel(int64_t n, int64_t nb, const T *L,
+                                                        int64_t ldl, const T *E, int64_t lde,
+                                                        const T *E2, int64_t lde2,
+                                                        const T *sigma_p, T *F, int64_t ldf, T *Y,
+                                                        int64_t ldy, int nrt, int nct, int vec_e,
+                                                        int vec_l) {
+  using M = Mfma<T>;
+  constexpr int DBK = TileK<T>::BK;
+  constexpr int FR = 64 / M::TM;
+  constexpr int LD = DBM + LdsPad<T>::V;
+  __shared__ __align__(16) T As[DBK * LD];
+  __shared__ __align__(16) T Bs[DBK * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ct = nct - 1 - (int)(blockIdx.x / nrt);  // heaviest column tiles first
+  const int rt = (int)(blockIdx.x % nrt);
+  const int64_t r0 = (int64_t)rt * DBM, c0 = (int64_t)ct * DBM;
+  const int64_t kend = (c0 + DBM < n) ? c0 + DBM : n;
+
+  LoaderKC<T, DBM, DBK> la;
+  LoaderKC<T, DBM, DBK, true> lb;
+  la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return (r0 + s < nb) ? E + (r0 + s) * lde : nullptr; }, E, tid);
+  lb.init([&](int s, int64_t &rg) -> const T * { rg = c0 + s; return (c0 + s < n) ? L + (c0 + s) * ldl : nullptr; }, L, tid);
+
+  typename M::acc_t acc[FR][FR];
+  zero_acc<T, FR, FR>(acc);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  la.load(0, 0, kend, vec_e, tid);
+  lb.load(0, 0, kend, vec_l, tid);
+  la.template store<LD>(As, tid);
+  lb.template store<LD>(Bs, tid);
+  __syncthreads();
+  for (int64_t k = 0; k < kend; k += DBK) {
+    const bool more = k + DBK < kend;
+    if (more) {
+      la.load(k + DBK, 0, kend, vec_e, tid);
+      lb.load(k + DBK, 0, kend, vec_l, tid);
+    }
+    mma_ktile<T, FR, FR, DBK, LD, LD>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+    if (more) {
+      la.template store<LD>(As, tid);
+      lb.template store<LD>(Bs, tid);
+      __syncthreads();
+    }
+  }
+  const T sigma = (E2 != nullptr) ? sigma_p[0] : T(0);
+#pragma unroll
+  for (int fm = 0; fm < FR; ++fm) {
+    T e2[M::NACC][FR];
+    if (E2 != nullptr) {  // all loads of this half first (clamped address), then the stores
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t row = r0 + wm + fm * M::TM + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < FR; ++fn) {
+          const int64_t c = c0 + wn + fn * M::TM + M::col(lane);
+          e2[r][fn] = E2[(row < nb && c < n) ? row * lde2 + c : 0];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      const int64_t row = r0 + wm + fm * M::TM + M::row(lane, r);
+#pragma unroll
+      for (int fn = 0; fn < FR; ++fn) {
+        const int64_t c = c0 + wn + fn * M::TM + M::col(lane);
+        if (row < nb && c < n) {
+          const T f = acc[fm][fn][r];
+          if (F != nullptr) F[row * ldf + c] = f;
+          if (Y != nullptr) Y[row * ldy + c] = (E2 != nullptr) ? f + sigma * e2[r][fn] : f;
+        }
+      }
+    }
+  }
+}
+
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------
+// counter = (i_lo, i_hi, stream_lo, stream_hi) with i = element index / 4, key = (seed_lo, seed_hi);
+// the 4 output words give 4 normals: (u0,u1) -> (r cos, r sin), (u2,u3) -> (r cos, r sin),
+// u = (word + 0.5) * 2^-32 in (0,1] (formed in T), r = sqrt(-2 ln u_even), angle = 2 pi u_odd.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+template <typename T>
+__global__ void randn_kernel(int64_t count, uint64_t seed, uint64_t stream_id, T *out) {
+  const int64_t nq = (count + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)stream_id,
+                     (uint32_t)(stream_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    T z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (sizeof(T) == 4) {
+        const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+        const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
+      } else {
+        const double u1 = ((double)c[2 * h] + 0.5) * (1.0 / 4294967296.0);
+        const double u2 = ((double)c[2 * h + 1] + 0.5) * (1.0 / 4294967296.0);
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincospi(2.0 * u2, &sn, &cs);
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
+      }
+    }
+    const int64_t i = q * 4;
+    if (i + 3 < count && ((reinterpret_cast<uintptr_t>(out + i) % (4 * sizeof(T))) == 0)) {
+      typename Vec4<T>::type v;
+      v.x = z[0]; v.y = z[1]; v.z = z[2]; v.w = z[3];
+      *reinterpret_cast<typename Vec4<T>::type *>(out + i) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i + e < count) out[i + e] = z[e];
+    }
+  }
+}
+
+}  // namespace gpvae
+
+using namespace gpvae;
+
+extern "C" int gpvae_draw(void *stream, int dtype, int64_t n, int64_t nb, const void *L,
+                          int64_t ldl, const void *E, int64_t lde, const void *E2, int64_t lde2,
+                          const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_draw: bad dtype %d", dtype);
+  GPVAE_REQUIRE(n >= 0, 3, "gpvae_draw: n < 0");
+  GPVAE_REQUIRE(nb >= 0, 4, "gpvae_draw: nb < 0");
+  if (n == 0 || nb == 0) return 0;
+  GPVAE_REQUIRE(L, 5, "gpvae_draw: L is NULL");
+  GPVAE_REQUIRE(ldl >= n, 6, "gpvae_draw: ldl < n");
+  GPVAE_REQUIRE(E, 7, "gpvae_draw: E is NULL");
+  GPVAE_REQUIRE(lde >= n, 8, "gpvae_draw: lde < n");
+  if (E2) {
+    GPVAE_REQUIRE(lde2 >= n, 10, "gpvae_draw: lde2 < n");
+    GPVAE_REQUIRE(sigma, 11, "gpvae_draw: sigma is NULL with E2 given");
+  }
+  GPVAE_REQUIRE(F || Y, 14, "gpvae_draw: both F and Y are NULL");
+  if (F) GPVAE_REQUIRE(ldf >= n, 13, "gpvae_draw: ldf < n");
+  if (Y) GPVAE_REQUIRE(ldy >= n, 15, "gpvae_draw: ldy < n");
+  const int64_t nrt = cdiv(nb, DBM), nct = cdiv(n, DBM);
+  GPVAE_REQUIRE(nrt * nct < (int64_t)1 << 31, 4, "gpvae_draw: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((draw_kernel<float>), dim3((unsigned)(nrt * nct)), dim3(NTHREADS), 0, st, n,
+                       nb, (const float *)L, ldl, (const float *)E, lde, (const float *)E2, lde2,
+                       (const float *)sigma, (float *)F, ldf, (float *)Y, ldy, (int)nrt, (int)nct,
+                       (int)kc_vec_ok<float>(E, lde), (int)kc_vec_ok<float>(L, ldl));
+  else
+    hipLaunchKernelGGL((draw_kernel<double>), dim3((unsigned)(nrt * nct)), dim3(NTHREADS), 0, st, n,
+                       nb, (const double *)L, ldl, (const double *)E, lde, (const double *)E2, lde2,
+                       (const double *)sigma, (double *)F, ldf, (double *)Y, ldy, (int)nrt,
+                       (int)nct, (int)kc_vec_ok<double>(E, lde), (int)kc_vec_ok<double>(L, ldl));
+  GPVAE_CHECK_LAUNCH("gpvae_draw");
+  return 0;
+}
+
+extern "C" int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed,
+                           uint64_t stream_id, void *out) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_randn: bad dtype %d", dtype);
+  GPVAE_REQUIRE(count >= 0, 3, "gpvae_randn: count < 0");
+  if (count == 0) return 0;
+  GPVAE_REQUIRE(out, 6, "gpvae_randn: out is NULL");
+  const int64_t nq = cdiv(count, 4);
+  int64_t blocks = cdiv(nq, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((randn_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, count, seed,
+                       stream_id, (float *)out);
+  else
+    hipLaunchKernelGGL((randn_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, count,
+                       seed, stream_id, (double *)out);
+  GPVAE_CHECK_LAUNCH("gpvae_randn");
+  return 0;
+}

@@ -1,0 +1,519 @@
+// potrf.hip — batched blocked Cholesky with trailing rows (kriging a9).
+//
+// Replaces the Cholesky that dist.MultivariateNormal(covariance_matrix=k) runs
+// (/root/reference/src/model/gp.py:190-193, inference.py:378-383,417-422) and, through the
+// trailing-row solve, the explicit inverse of gp_prediction (inference.py:450-455).
+//
+// Two-level blocking, two kernels, no inter-workgroup hand-off inside a launch:
+//   outer block NBO = 256 columns, right-looking:  potrf_syrk_kernel  C -= P P^T   (MFMA, K = 256;
+//       >= 89 % of the flops at n = 4096; 128x128 tiles => 128 flop/byte of C traffic in f32)
+//   inner block NB = 64 columns, left-looking inside the outer block: potrf_panel_kernel, ONE launch
+//       per 64 columns.  Every workgroup (a) applies the outer block's earlier columns to the 64x64
+//       diagonal block and to its own 64-row chunks with MFMA, (b) factors the diagonal block in LDS
+//       (one wave, lane = row, row of L broadcast from LDS, 64 unrolled column steps), (c) solves
+//       its chunks X L11^T = C with the same lane = row sweep, one chunk per wave.
+//       The diagonal block is factored redundantly by every workgroup: that costs no wall time and
+//       removes the launch boundary a separate "diagonal" kernel would need.
+// "Virtual rows": rows >= n come from a second array X (m_extra rows of length n); they ride along
+// as extra chunks and come out as X L^-T — the right-hand solve kriging needs — for free.
+// Rows/cols between n and the next multiple of 64 behave as an identity block.
+#include "gemm_core.hpp"
+
+namespace gpvae {
+
+constexpr int NB = 64;     // inner (panel) block
+constexpr int NBO = 256;   // outer block
+
+// developer probe: when set (gpvae_dev_set_stamps), block (0,0) of every panel launch writes
+// s_memtime at its phase boundaries to stamps[0..7]
+static unsigned long long *g_stamps = nullptr;
+#define STAMP(i)                                                                   \
+  do {                                                                             \
+    if (stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)       \
+      stamps[i] = __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+
+template <typename T> struct VRows {
+  T *A;
+  int64_t lda, n;
+  T *X;
+  int64_t ldx, npad, mx;
+  __device__ __forceinline__ T *ptr(int64_t vr) const {
+    if (vr < n) return A + vr * lda;
+    const int64_t e = vr - npad;
+    return (e >= 0 && e < mx) ? X + e * ldx : nullptr;
+  }
+};
+
+template <typename T> struct PanelCfg;
+template <> struct PanelCfg<float> {
+  static constexpr int BK = 32;  // k-tile of the staged update GEMM
+  static constexpr int NCH = 4;  // 64-row chunks per workgroup (one per wave in the solve)
+  static constexpr int S = 68;   // LDS row stride of the 64-wide blocks (16-B aligned rows,
+                                 // ds_read_b128 of one row per lane is conflict free: 17 slots/row)
+};
+template <> struct PanelCfg<double> {
+  static constexpr int BK = 16;
+  static constexpr int NCH = 2;
+  static constexpr int S = 66;
+};
+
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int j);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x): v_rsq_f32 is accurate to 1 ulp; v_rsq_f64 is a ~26-bit seed refined by two Newton
+// steps.  Negative or NaN input gives NaN, zero gives +inf — both poison the column, as wanted.
+template <typename T> __device__ __forceinline__ T fast_rsqrt(T x);
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
+  return __builtin_amdgcn_rsqf(x);
+}
+template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-x * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+  }
+  return r;
+}
+
+// lane = row sweep.  x[0..63]: the lane's row of the block (in: right-hand side, out: solution).
+// Lrow: LDS [64][S] rows of L11;  rdiag: LDS [64] reciprocals of diag(L11).
+// DIAG = true factors the block itself (x is the row of the symmetric block; L11 and rdiag are
+// produced);  DIAG = false solves x L11^T = c for a row below the block.
+// zoff is a per-lane zero the compiler cannot see through: it keeps the broadcast LDS reads of a
+// row of L in VGPRs (a provably uniform address makes hipcc add a v_readlane per value).
+// Returns (DIAG only) the first column whose pivot was not > 0, or -1.
+template <typename T, int S, bool DIAG>
+__device__ __forceinline__ int tri_rows(T (&x)[NB], T *Lrow, T *rdiag, int lane, int zoff) {
+  constexpr int VEC = VecT<T>::N;
+  using V = typename VecT<T>::type;
+  int fail = -1;
+  if constexpr (DIAG) {
+    T cur[NB], nxt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      // rows of L are final up to column j-1: fetch row j+1's known part while step j computes
+      if (j + 1 < NB) {
+#pragma unroll
+        for (int k = 0; k < j; k += VEC) {
+          const V t = *reinterpret_cast<const V *>(&Lrow[(j + 1) * S + k + zoff]);
+          const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) nxt[k + e] = tp[e];
+        }
+      }
+      T acc[4] = {x[j], T(0), T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < j; ++k) acc[k & 3] -= x[k] * cur[k];
+      const T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      const T piv = lane_bcast<T>(s, j);
+      if (!(piv > T(0)) && fail < 0) fail = j;
+      const T rd = fast_rsqrt<T>(piv);
+      T v = (lane > j) ? s * rd : T(0);
+      if (lane == j) v = piv * rd;
+      x[j] = v;
+      Lrow[lane * S + j] = v;
+      if (lane == 0) rdiag[j] = rd;
+      if (j + 1 < NB) {
+        nxt[j] = lane_bcast<T>(v, j + 1);
+#pragma unroll
+        for (int k = 0; k <= j; ++k) cur[k] = nxt[k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      T acc[4] = {x[j], T(0), T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < j; k += VEC) {
+        const V t = *reinterpret_cast<const V *>(&Lrow[j * S + k + zoff]);
+        const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (k + e < j) acc[(k + e) & 3] -= x[k + e] * tp[e];
+      }
+      x[j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[j + zoff];
+    }
+  }
+  return fail;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
+                                                               int64_t strideX, int64_t c0,
+                                                               int64_t cJ, int32_t *info, int vec,
+                                                               unsigned long long *stamps) {
+  using M = Mfma<T>;
+  using Cfg = PanelCfg<T>;
+  constexpr int NCH = Cfg::NCH, S = Cfg::S, PBK = Cfg::BK;
+  constexpr int SROWS = NB + NB * NCH;              // stacked rows: diagonal block + chunks
+  constexpr int LDT = SROWS + LdsPad<T>::V;         // k-major staging stride
+  constexpr int RPW = 16 * NCH;                     // chunk rows per wave in the GEMM phase
+  constexpr int FM = RPW / M::TM;                   // = 2 for both types
+  constexpr int FN = NB / M::TM;                    // 2 (f32) / 4 (f64)
+  constexpr int DN = (M::TM == 32) ? 1 : 4;         // diagonal-block tiles per wave
+  constexpr int VEC = VecT<T>::N;
+  constexpr int VPR = NB / VEC;                     // vectors per 64-wide row
+  using V = typename VecT<T>::type;
+  static_assert(FM == 2, "chunk rows per wave");
+  static_assert((SROWS * VPR) % NTHREADS == 0, "copy-in tiling");
+
+  __shared__ __align__(16) T Blk[SROWS * S];   // [diag block (64 rows); chunks] row-major, stride S
+  __shared__ __align__(16) T stage[PBK * LDT];
+  __shared__ T rdiag[NB];
+  T *Dm = Blk, *Cw = Blk + NB * S;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  vr.A += (int64_t)b * strideA;
+  if (vr.X) vr.X += (int64_t)b * strideX;
+  const int64_t n = vr.n;
+  const int64_t rbase = c0 + NB + (int64_t)blockIdx.x * NB * NCH;  // first chunk row (virtual)
+  const int64_t Mv = vr.npad + vr.mx;
+
+  STAMP(0);
+  int zoff;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+  const int dm0 = (M::TM == 32) ? (wave >> 1) * 32 : wave * 16;
+  const int dn0 = (M::TM == 32) ? (wave & 1) * 32 : 0;
+  const bool vcols = vec && (c0 + NB <= n);  // the 64 columns are whole and 16-byte aligned
+
+  // ---- copy [D; C] (columns c0..c0+63 of the stacked rows) global -> LDS, 16 bytes per lane ------
+  // branch-free (clamped pointer + select) so every load is in flight at once
+  {
+    constexpr int NVC = SROWS * VPR / NTHREADS;
+    T tmp[NVC][VEC];
+#pragma unroll
+    for (int p = 0; p < NVC; ++p) {
+      const int v = tid + p * NTHREADS;
+      const int s = v / VPR, j = (v % VPR) * VEC;
+      const int64_t vrow = (s < NB) ? c0 + s : rbase + (s - NB);
+      const T *rp = vr.ptr(vrow);
+      const bool rok = rp != nullptr;
+      const T *src = (rok ? rp : vr.A) + c0 + j;
+      if (vcols) {
+        const V t = *reinterpret_cast<const V *>(src);
+        const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tmp[p][e] = rok ? tp[e] : T(0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const bool in = rok && c0 + j + e < n;
+          tmp[p][e] = in ? src[in ? e : -(c0 + j)] : T(0);
+        }
+      }
+      if (s < NB) {  // rows/cols past n act as an identity block
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if ((vrow >= n || c0 + j + e >= n)) tmp[p][e] = (s == j + e) ? T(1) : T(0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NVC; ++p) {
+      const int v = tid + p * NTHREADS;
+      const int s = v / VPR, j = (v % VPR) * VEC;
+      V t;
+      T *tp = reinterpret_cast<T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tp[e] = tmp[p][e];
+      *reinterpret_cast<V *>(&Blk[s * S + j]) = t;
+    }
+  }
+
+  // ---- (a) apply columns [cJ, c0) of the outer block: [D; C] -= [Pd; Pc] Pd^T ------------------
+  if (c0 > cJ) {
+    typename M::acc_t accC[FM][FN];
+    typename M::acc_t accD[1][DN];
+    zero_acc<T, FM, FN>(accC);
+    zero_acc<T, 1, DN>(accD);
+    LoaderKC<T, SROWS, PBK> ld;
+    ld.init(
+        [&](int s, int64_t &rg) -> const T * {
+          const int64_t vrow = (s < NB) ? c0 + s : rbase + (s - NB);
+          rg = vrow;
+          return vr.ptr(vrow);
+        },
+        vr.A, tid);
+    ld.load(cJ, cJ, c0, vec, tid);
+    ld.template store<LDT>(stage, tid);
+    __syncthreads();
+    for (int64_t k = cJ; k < c0; k += PBK) {
+      const bool more = k + PBK < c0;
+      if (more) ld.load(k + PBK, cJ, c0, vec, tid);
+      mma_ktile<T, FM, FN, PBK, LDT, LDT>(stage, stage, NB + wave * RPW, 0, lane, accC);
+      mma_ktile<T, 1, DN, PBK, LDT, LDT>(stage, stage, dm0, dn0, lane, accD);
+      __syncthreads();
+      if (more) {
+        ld.template store<LDT>(stage, tid);
+        __syncthreads();
+      }
+    }
+    STAMP(1);
+    // subtract the products from the LDS image; every element belongs to exactly one lane
+#pragma unroll
+    for (int fn = 0; fn < DN; ++fn)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int i = dm0 + M::row(lane, r), j = dn0 + fn * M::TM + M::col(lane);
+        Dm[i * S + j] -= accD[0][fn][r];
+      }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int ci = wave * RPW + fm * M::TM + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) Cw[ci * S + fn * M::TM + M::col(lane)] -= accC[fm][fn][r];
+      }
+  }
+  __syncthreads();
+  STAMP(2);
+
+  // ---- (b) factor the diagonal block: wave 0, lane = row ----------------------------------------
+  if (wave == 0) {
+    T x[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k += VEC) {
+      const V t = *reinterpret_cast<const V *>(&Dm[lane * S + k]);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[k + e] = tp[e];
+    }
+    const int fail = tri_rows<T, S, true>(x, Dm, rdiag, lane, zoff);
+    if (blockIdx.x == 0 && lane == 0 && fail >= 0 && c0 + fail < n) {
+      if (info[b] == 0) info[b] = (int32_t)(c0 + fail + 1);
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+
+  // ---- (c) solve the chunks: one chunk per wave, lane = row -----------------------------------
+  if (wave < NCH && rbase + wave * NB < Mv) {
+    T x[NB];
+    T *row = &Cw[(wave * NB + lane) * S];
+#pragma unroll
+    for (int k = 0; k < NB; k += VEC) {
+      const V t = *reinterpret_cast<const V *>(&row[k]);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[k + e] = tp[e];
+    }
+    tri_rows<T, S, false>(x, Dm, rdiag, lane, zoff);
+#pragma unroll
+    for (int k = 0; k < NB; k += VEC) {
+      V t;
+      T *tp = reinterpret_cast<T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tp[e] = x[k + e];
+      *reinterpret_cast<V *>(&row[k]) = t;
+    }
+  }
+  __syncthreads();
+  STAMP(4);
+
+  // ---- coalesced stores ---------------------------------------------------------------------------
+  for (int idx = tid; idx < (NCH + (blockIdx.x == 0 ? 1 : 0)) * NB * VPR; idx += NTHREADS) {
+    const int s = idx / VPR, j = (idx % VPR) * VEC;  // s < NCH*NB: chunk rows; beyond: L11 (block 0)
+    const bool is_l11 = s >= NCH * NB;
+    const int li = s - NCH * NB;
+    T *rp = is_l11 ? vr.ptr(c0 + li) : vr.ptr(rbase + s);
+    if (rp == nullptr) continue;
+    V t = *reinterpret_cast<const V *>(is_l11 ? &Dm[li * S + j] : &Cw[s * S + j]);
+    T *tp = reinterpret_cast<T *>(&t);
+    if (is_l11) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (j + e > li) tp[e] = T(0);  // clean upper triangle inside the diagonal block
+    }
+    T *dst = rp + c0 + j;
+    if (vcols) {
+      *reinterpret_cast<V *>(dst) = t;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (c0 + j + e < n) dst[e] = tp[e];
+    }
+  }
+  STAMP(5);
+}
+
+// ---- outer trailing update: C[r][c] -= sum_{k in [cJ, cJ+kb)} P[r][k] P[c][k] ----------------------
+// 128x128 tiles, 4 waves as 2x2, each 64x64.  Grid (row tiles, col tiles, batch); tiles strictly
+// above the diagonal exit at once.
+constexpr int SBM = 128;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void potrf_syrk_kernel(VRows<T> vr, int64_t strideA,
+                                                              int64_t strideX, int64_t cJ,
+                                                              int64_t kend, int vec) {
+  using M = Mfma<T>;
+  constexpr int SBK = TileK<T>::BK;
+  constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
+  constexpr int LD = SBM + LdsPad<T>::V;
+  if (blockIdx.x < blockIdx.y) return;
+  __shared__ __align__(16) T As[SBK * LD];
+  __shared__ __align__(16) T Bs[SBK * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  vr.A += (int64_t)b * strideA;
+  if (vr.X) vr.X += (int64_t)b * strideX;
+  const int64_t n = vr.n;
+  const int64_t r0 = kend + (int64_t)blockIdx.x * SBM;  // first virtual row of the tile
+  const int64_t q0 = kend + (int64_t)blockIdx.y * SBM;  // first column of the tile (< n)
+  const bool diag_tile = blockIdx.x == blockIdx.y;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  LoaderKC<T, SBM, SBK> la, lb;
+  la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return vr.ptr(r0 + s); }, vr.A, tid);
+  lb.init([&](int s, int64_t &rg) -> const T * { rg = q0 + s; return (q0 + s < n) ? vr.A + (q0 + s) * vr.lda : nullptr; }, vr.A, tid);
+  la.load(cJ, cJ, kend, vec, tid);
+  lb.load(cJ, cJ, kend, vec, tid);
+
+  // the accumulators start from C (loads in flight together with the first operand tile) and the
+  // A operand is negated on its way into LDS:  acc = C + (-P_r) P_c^T
+  typename M::acc_t acc[F][F];
+#pragma unroll
+  for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      const T *rp = vr.ptr(r0 + wm + fm * M::TM + M::row(lane, r));
+#pragma unroll
+      for (int fn = 0; fn < F; ++fn) {
+        const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
+        acc[fm][fn][r] = (rp != nullptr && c < n) ? rp[c] : vr.A[0];
+      }
+    }
+
+  la.template store<LD, true>(As, tid);
+  lb.template store<LD>(Bs, tid);
+  __syncthreads();
+  for (int64_t k = cJ; k < kend; k += SBK) {
+    const bool more = k + SBK < kend;
+    if (more) {
+      la.load(k + SBK, cJ, kend, vec, tid);
+      lb.load(k + SBK, cJ, kend, vec, tid);
+    }
+    mma_ktile<T, F, F, SBK, LD, LD>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+    if (more) {
+      la.template store<LD, true>(As, tid);
+      lb.template store<LD>(Bs, tid);
+      __syncthreads();
+    }
+  }
+  // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: nothing to store
+  if (diag_tile && wm == 0 && wn == 64) return;
+#pragma unroll
+  for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      T *rp = vr.ptr(r0 + wm + fm * M::TM + M::row(lane, r));
+#pragma unroll
+      for (int fn = 0; fn < F; ++fn) {
+        const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
+        if (rp != nullptr && c < n) rp[c] = acc[fm][fn][r];
+      }
+    }
+}
+
+// ---- finalize: zero the strict upper triangle; NaN-fill failed matrices -------------------------------
+template <typename T>
+__global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_t n,
+                                      const int32_t *info, int flags) {
+  const int b = blockIdx.z;
+  T *Ab = A + (int64_t)b * strideA;
+  const bool failed = (flags & GPVAE_POTRF_NAN_ON_FAIL) && info[b] != 0;
+  const bool zero_up = flags & GPVAE_POTRF_ZERO_UPPER;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int64_t i0 = (int64_t)blockIdx.y * 64;
+  const int64_t i1 = (i0 + 64 < n) ? i0 + 64 : n;
+  if (!failed && (!zero_up || j <= i0)) return;  // nothing to do for this column strip
+  for (int64_t i = i0; i < i1; ++i) {
+    if (failed) Ab[i * lda + j] = dnan<T>();
+    else if (j > i) Ab[i * lda + j] = T(0);
+  }
+}
+
+template <typename T>
+static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                     int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags) {
+  constexpr int NCH = PanelCfg<T>::NCH;
+  VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
+  const int64_t Mv = vr.npad + mx;
+  constexpr int VEC = VecT<T>::N;
+  const int vec = kc_vec_ok<T>(A, lda) && (strideA % VEC == 0) &&
+                  (mx == 0 || (kc_vec_ok<T>(X, ldx) && (strideX % VEC == 0)));
+  if (hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
+    set_error("gpvae_potrf: hipMemsetAsync(info) failed");
+    return -12;
+  }
+  for (int64_t cJ = 0; cJ < n; cJ += NBO) {
+    const int64_t kend = (cJ + NBO < n) ? cJ + NBO : n;
+    for (int64_t c0 = cJ; c0 < kend; c0 += NB) {
+      const int64_t below = Mv - (c0 + NB);
+      const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
+      hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)nwg, (unsigned)batch),
+                         dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, vec, g_stamps);
+    }
+    if (kend < n) {
+      const int64_t rt = cdiv(Mv - kend, SBM), ct = cdiv(n - kend, SBM);
+      hipLaunchKernelGGL((potrf_syrk_kernel<T>), dim3((unsigned)rt, (unsigned)ct, (unsigned)batch),
+                         dim3(NTHREADS), 0, st, vr, strideA, strideX, cJ, kend, vec);
+    }
+  }
+  if (flags & (GPVAE_POTRF_ZERO_UPPER | GPVAE_POTRF_NAN_ON_FAIL)) {
+    hipLaunchKernelGGL((potrf_finalize_kernel<T>),
+                       dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(n, 64), (unsigned)batch),
+                       dim3(256), 0, st, (T *)A, lda, strideA, n, info, flags);
+  }
+  GPVAE_CHECK_LAUNCH("gpvae_potrf");
+  return 0;
+}
+
+}  // namespace gpvae
+
+using namespace gpvae;
+
+extern "C" void gpvae_dev_set_stamps(void *p) { gpvae::g_stamps = (unsigned long long *)p; }
+
+extern "C" int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch) {
+  (void)dtype; (void)n; (void)m_extra; (void)batch;
+  return 0;  // the factorisation is in place; kept in the ABI so a blocked variant may use scratch
+}
+
+extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
+                           int64_t strideA, int64_t m_extra, void *X, int64_t ldx,
+                           int64_t strideX, int32_t *info, int flags, void *work) {
+  (void)work;
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_potrf: bad dtype %d", dtype);
+  GPVAE_REQUIRE(n >= 0, 3, "gpvae_potrf: n < 0");
+  GPVAE_REQUIRE(batch >= 0 && batch <= 65535, 4, "gpvae_potrf: batch out of range [0,65535]");
+  GPVAE_REQUIRE(m_extra >= 0, 8, "gpvae_potrf: m_extra < 0");
+  if (n == 0 || batch == 0) return 0;
+  GPVAE_REQUIRE(A, 5, "gpvae_potrf: A is NULL");
+  GPVAE_REQUIRE(lda >= n, 6, "gpvae_potrf: lda < n");
+  GPVAE_REQUIRE(batch == 1 || strideA >= n * lda, 7, "gpvae_potrf: strideA < n*lda");
+  if (m_extra > 0) {
+    GPVAE_REQUIRE(X, 9, "gpvae_potrf: X is NULL with m_extra > 0");
+    GPVAE_REQUIRE(ldx >= n, 10, "gpvae_potrf: ldx < n");
+    GPVAE_REQUIRE(batch == 1 || strideX >= m_extra * ldx, 11, "gpvae_potrf: strideX too small");
+  }
+  GPVAE_REQUIRE(info, 12, "gpvae_potrf: info is NULL");
+  GPVAE_REQUIRE(cdiv(round_up(n, NB) + m_extra, SBM) <= 65535, 3, "gpvae_potrf: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (m_extra == 0) X = nullptr;
+  return dtype == GPVAE_F32
+             ? run_potrf<float>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info, flags)
+             : run_potrf<double>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info,
+                                 flags);
+}

@@ -1,0 +1,153 @@
+"""Thin torch-tensor front end of the C ABI (include/gpvae.h).
+
+torch is used for device memory and streams only: every function here passes raw device pointers
+of caller-visible tensors to libgpvae_hip.so on torch's current HIP stream.  No arithmetic happens
+in torch and nothing falls back to the CPU: a CPU tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import F32, F64, GpvaeError, POTRF_NAN_ON_FAIL, POTRF_ZERO_UPPER, check
+
+_DT = {torch.float32: F32, torch.float64: F64}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise GpvaeError("unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise GpvaeError("libgpvae_hip needs device (HIP) tensors; got a %s tensor" % t.device)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def scalar(v, like=None, dtype=None, device=None):
+    """Device scalar (shape [1]) for the ABI's `const void *var` style arguments."""
+    dtype = dtype or like.dtype
+    device = device or like.device
+    if isinstance(v, torch.Tensor):
+        return v.to(device=device, dtype=dtype).reshape(-1).contiguous()
+    return torch.tensor([float(v)], dtype=dtype, device=device)
+
+
+def _points(x):
+    """check_d of the reference (gp.py:30-41): a 1-D array is a column of 1-D locations."""
+    if x.dim() == 1:
+        x = x.reshape(-1, 1)
+    if x.dim() != 2 or x.shape[1] not in (1, 2):
+        raise GpvaeError("locations must be [n] or [n,d] with d in {1,2}; got %s" % (tuple(x.shape),))
+    return x.contiguous()
+
+
+def gram_se(x, z, var, ls, jitter=1.0e-5, out=None):
+    """K[b] = var[b]*exp(-0.5*(|x_i-z_j|/ls[b])^2) (+jitter*I iff square).  var/ls: scalars or [batch].
+
+    Returns [n_x, n_z] for scalar hyper-parameters, [batch, n_x, n_z] for vectors."""
+    _dev(x, z)
+    if x.dim() != z.dim():
+        raise GpvaeError("x and z must have the same number of dimensions (gp.py:34)")
+    x, z = _points(x), _points(z)
+    if x.shape[1] != z.shape[1] or x.dtype != z.dtype:
+        raise GpvaeError("x and z disagree in d or dtype")
+    batched = isinstance(var, torch.Tensor) and var.numel() > 1 or \
+        isinstance(ls, torch.Tensor) and ls.numel() > 1
+    var_t, ls_t = scalar(var, x), scalar(ls, x)
+    batch = max(var_t.numel(), ls_t.numel())
+    if var_t.numel() != batch:
+        var_t = var_t.expand(batch).contiguous()
+    if ls_t.numel() != batch:
+        ls_t = ls_t.expand(batch).contiguous()
+    n_x, n_z = x.shape[0], z.shape[0]
+    if out is None:
+        out = torch.empty((batch, n_x, n_z), dtype=x.dtype, device=x.device)
+    K = out.view(batch, n_x, n_z)
+    lib = _lib.load()
+    check(lib.gpvae_gram_se(_stream(), _dt(x), x.shape[1], n_x, n_z, _p(x), _p(z), batch, _p(var_t),
+                            _p(ls_t), float(jitter), _p(K), K.stride(1), K.stride(0)),
+          "gpvae_gram_se")
+    return K if batched else K[0]
+
+
+def gram_agg(pts, var, ls, jitter=1.0e-6):
+    """Aggregated kernel from sample points pts [n_cells, m, d] (agg_kernel_grid, gp.py:119-127)."""
+    _dev(pts)
+    if pts.dim() != 3 or pts.shape[2] not in (1, 2):
+        raise GpvaeError("pts must be [n_cells, m, d]")
+    pts = pts.contiguous()
+    n_cells, m, d = pts.shape
+    K = torch.empty((n_cells, n_cells), dtype=pts.dtype, device=pts.device)
+    lib = _lib.load()
+    check(lib.gpvae_gram_agg(_stream(), _dt(pts), d, n_cells, m, _p(pts), _p(scalar(var, pts)),
+                             _p(scalar(ls, pts)), float(jitter), _p(K), K.stride(0)),
+          "gpvae_gram_agg")
+    return K
+
+
+def potrf_(A, X=None, zero_upper=True, nan_on_fail=True):
+    """In-place lower Cholesky of A [n,n] or [batch,n,n]; X ([.., m, n]) becomes X L^-T.
+
+    Returns the int32 info tensor [batch] (device; 0 = ok, j = leading minor j not PD)."""
+    _dev(A, X)
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    if A3.shape[1] != A3.shape[2] or A3.stride(2) != 1:
+        raise GpvaeError("A must be [batch,n,n] with unit column stride")
+    batch, n = A3.shape[0], A3.shape[1]
+    m = 0
+    X3 = None
+    if X is not None:
+        X3 = X if X.dim() == 3 else X.unsqueeze(0)
+        if X3.shape[0] != batch or X3.shape[2] != n or X3.stride(2) != 1 or X3.dtype != A.dtype:
+            raise GpvaeError("X must be [batch,m,n], same dtype, unit column stride")
+        m = X3.shape[1]
+    info = torch.empty((batch,), dtype=torch.int32, device=A.device)
+    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    lib = _lib.load()
+    check(lib.gpvae_potrf(_stream(), _dt(A), n, batch, _p(A3), A3.stride(1), A3.stride(0), m,
+                          _p(X3), X3.stride(1) if m else 0, X3.stride(0) if m else 0, _p(info),
+                          flags, C.c_void_p(0)), "gpvae_potrf")
+    return info
+
+
+def draw(L, E, E2=None, sigma=None, want_f=False):
+    """Y = E L^T (+ sigma*E2).  L [n,n] lower factor, E/E2 [nb,n].  Returns Y or (F, Y)."""
+    _dev(L, E, E2)
+    n, nb = L.shape[0], E.shape[0]
+    if L.shape != (n, n) or E.shape[1] != n or L.stride(1) != 1 or E.stride(1) != 1:
+        raise GpvaeError("draw: L must be [n,n], E [nb,n], unit column strides")
+    if E2 is not None and (E2.shape != E.shape or E2.stride(1) != 1):
+        raise GpvaeError("draw: E2 must match E")
+    Y = torch.empty((nb, n), dtype=L.dtype, device=L.device)
+    F = torch.empty((nb, n), dtype=L.dtype, device=L.device) if want_f else None
+    sig = scalar(sigma, L) if E2 is not None else None
+    lib = _lib.load()
+    check(lib.gpvae_draw(_stream(), _dt(L), n, nb, _p(L), L.stride(0), _p(E), E.stride(0), _p(E2),
+                         E2.stride(0) if E2 is not None else 0, _p(sig), _p(F),
+                         F.stride(0) if want_f else 0, _p(Y), Y.stride(0)), "gpvae_draw")
+    return (F, Y) if want_f else Y
+
+
+def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=None):
+    """Philox4x32-10 / Box-Muller standard normals; element i depends only on (seed, stream_id, i)."""
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=device)
+    _dev(out)
+    if not out.is_contiguous():
+        raise GpvaeError("randn: out must be contiguous")
+    lib = _lib.load()
+    check(lib.gpvae_randn(_stream(), _dt(out), out.numel(), int(seed), int(stream_id), _p(out)),
+          "gpvae_randn")
+    return out

@@ -1,0 +1,143 @@
+/*
+ * gpvae.h — C ABI of libgpvae_hip.so: the MI355X (gfx950) hot path of edenx/gp-vae.
+ *
+ * The reference (/root/reference, pure JAX/NumPyro) has no FFI of its own; its seams are Python
+ * callables.  Each entry point below names the reference call site whose arithmetic
+ * it replaces (file:line under /root/reference).  INTEGRATION.md shows the ctypes / JAX-FFI binding
+ * a maintainer would add on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch / no C++ types; every pointer except `stream` is a DEVICE pointer owned by
+ *     the caller; matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous and
+ *     stream-ordered, never synchronise the device and never allocate device memory
+ *     (workspaces are caller-provided; sizes come from the *_workspace_bytes queries);
+ *   - `dtype` selects the arithmetic type: GPVAE_F32 (the reference's type) or GPVAE_F64;
+ *   - return value: 0 = launched; <0 = -(1-based index of the first bad argument); numerical
+ *     failures are reported through device-side `info` words (LAPACK style), never through the
+ *     return value, because the call does not wait for the device;
+ *   - gpvae_last_error() returns a thread-local, human-readable reason for the last non-zero return.
+ */
+#ifndef GPVAE_H
+#define GPVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPVAE_ABI_VERSION 1
+
+enum { GPVAE_F32 = 0, GPVAE_F64 = 1 };
+
+/* gpvae_potrf flags */
+enum {
+  GPVAE_POTRF_ZERO_UPPER = 1, /* clear the strict upper triangle (JAX returns a clean lower factor) */
+  GPVAE_POTRF_NAN_ON_FAIL = 2 /* a non-PD matrix comes back all-NaN (jnp.linalg.cholesky semantics) */
+};
+
+int gpvae_abi_version(void);
+const char *gpvae_last_error(void);
+
+/* ---- a1: squared-exponential Gram matrix --------------------------------------------------------
+ * Replaces exp_kernel2 (src/model/gp.py:44-81) incl. check_d's 1-D reshape (gp.py:30-41):
+ *   K[b][i][j] = var[b] * exp(-0.5 * (||x_i - z_j||_2 / ls[b])^2)  (+ jitter on i==j iff n_x == n_z,
+ *   the reference's "square => add jitter*I" rule, gp.py:79-80).
+ * x: [n_x, d], z: [n_z, d] (d in {1,2}; contiguous), var, ls: device arrays of length `batch`.
+ * K: [batch][n_x][ldk]; matrix b starts at K + b*strideK elements.
+ * Bound: HBM write bandwidth; algorithmic bytes = batch*n_x*n_z*sizeof(T).                        */
+int gpvae_gram_se(void *stream, int dtype, int d, int64_t n_x, int64_t n_z, const void *x,
+                  const void *z, int batch, const void *var, const void *ls, double jitter,
+                  void *K, int64_t ldk, int64_t strideK);
+
+/* ---- a2: aggregated (cell-averaged) kernel -------------------------------------------------------
+ * Replaces agg_kernel_grid (src/model/gp.py:85-127) with the Uniform draws made an input:
+ *   K*[i][j] = (1/m^2) sum_{a,b} var*exp(-0.5*(||p_ia - p_jb||/ls)^2) + jitter/m
+ * pts: [n_cells, m, d] sample locations (origin_i + U/n, gp.py:103-113).  The "+jitter/m on every
+ * entry" term is what the literal code computes (every m x m block is square);
+ * pass jitter = 0 to get the intended average.  var, ls: device scalars.                          */
+int gpvae_gram_agg(void *stream, int dtype, int d, int64_t n_cells, int m, const void *pts,
+                   const void *var, const void *ls, double jitter, void *K, int64_t ldk);
+
+/* ---- a3: batched blocked Cholesky (+ trailing rows) ----------------------------------------------
+ * Replaces the Cholesky inside dist.MultivariateNormal(covariance_matrix=k) (gp.py:190-193,
+ * inference.py:378-383, 417-422) and the jnp.linalg.inv of gp_prediction (inference.py:450).
+ * In place: the lower triangle of A[b] ([n, lda]) is overwritten by L with A = L L^T.
+ * If m_extra > 0, X[b] ([m_extra, ldx]) is overwritten by X L^-T (the right-side triangular solve
+ * the kriging path needs: rows of k_px and y^T) — the same panel sweep, no second pass over L.
+ * info[b] (int32): 0 = ok, j>0 = leading minor j not positive definite (LAPACK potrf).
+ * work: gpvae_potrf_workspace_bytes() bytes (may be NULL when that is 0).                          */
+int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch);
+int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
+                int64_t strideA, int64_t m_extra, void *X, int64_t ldx, int64_t strideX,
+                int32_t *info, int flags, void *work);
+
+/* ---- a3/a4: MVN draws ---------------------------------------------------------------------------
+ * Replaces f = L eps; y = f + sigma*eps' of GP.sample under Predictive (gp.py:190-194,
+ * vae.py:160-162,223-226): for nb draws sharing one factor,
+ *   F[r][i] = sum_{j<=i} E[r][j] * L[i][j];   Y = F + sigma * E2   (E2 may be NULL => Y = F).
+ * Only the lower triangle of L is read (the strict upper part may hold anything).
+ * F may be NULL (only y is wanted).  sigma: device scalar.                                         */
+int gpvae_draw(void *stream, int dtype, int64_t n, int64_t nb, const void *L, int64_t ldl,
+               const void *E, int64_t lde, const void *E2, int64_t lde2, const void *sigma,
+               void *F, int64_t ldf, void *Y, int64_t ldy);
+
+/* ---- f3: counter-based standard normals (Philox4x32-10 + Box-Muller) -------------------------------
+ * Stands in for jax.random.normal (threefry; not reproducible without JAX) in
+ * throughput runs; element i depends only on (seed, stream_id, i).                                */
+int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
+                void *out);
+
+/* ---- a9: kriging prediction ---------------------------------------------------------------------
+ * Replaces GPInference.gp_prediction (src/model/inference.py:427-460), literal quirks kept:
+ *   A = k_xx + jitter*I + sigma*I   (sigma, not sigma^2: inference.py:450)
+ *   mean = k_px A^-1 y_obs;  v = diag(k_pp - k_px A^-1 k_px^T), diag(k_pp) = var + jitter;
+ *   sample = mean + sqrt(max(v,0)) * xi.
+ * x_obs [n_obs,d], x_test [n_test,d], y_obs [n_obs], xi [n_test] (standard normals; may be NULL =>
+ * sample = mean); var, ls, sigma: device scalars.  Outputs mean, sample, var_out: [n_test] (any may
+ * be NULL).  Jitter is also added to k_px's "diagonal" when n_test == n_obs (the reference's
+ * square rule).  work: gpvae_krig_workspace_bytes() bytes.  info: int32, potrf status.            */
+int64_t gpvae_krig_workspace_bytes(int dtype, int64_t n_obs, int64_t n_test);
+int gpvae_krig_predict(void *stream, int dtype, int d, int64_t n_obs, int64_t n_test,
+                       const void *x_obs, const void *x_test, const void *y_obs, const void *var,
+                       const void *ls, const void *sigma, double jitter, const void *xi, void *mean,
+                       void *sample, void *var_out, int32_t *info, void *work);
+
+/* ---- a5+a6: VAE ELBO forward (+ backward) ---------------------------------------------------------
+ * Replaces vae_encoder/vae_decoder (src/model/vae.py:72-96) and vae_model+vae_guide under
+ * Trace_ELBO (vae.py:98-137,213-218): one-particle ELBO summed over batch and dims, obs noise
+ * `obs_sigma` (0.1 at vae.py:117).
+ * Parameters live in ONE flat device array `params` in this order (weights stored (in,out) row
+ * major as stax does):  W1[n,h0] b1[h0] W2[h0,h1] b2[h1] Wmu[h1,z] bmu[z] Wsd[h1,z] bsd[z]
+ *                       V1[z,h1] c1[h1] V2[h1,h0] c2[h0] V3[h0,n] c3[n]
+ * (gpvae_vae_param_count gives the length).  Y: [B, ldy] data, eps_z: [B, z] standard normals.
+ * loss: device scalar (overwritten).  grads: flat array like params (overwritten) or NULL for a
+ * forward-only evaluation (svi.evaluate, vae.py:194).  work: gpvae_vae_workspace_bytes() bytes.   */
+int64_t gpvae_vae_param_count(int64_t n, int h0, int h1, int z);
+int64_t gpvae_vae_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1, int z);
+int gpvae_vae_elbo(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,
+                   const void *params, const void *Y, int64_t ldy, const void *eps_z,
+                   double obs_sigma, void *loss, void *grads, void *work);
+
+/* ---- a7: Adam -----------------------------------------------------------------------------------
+ * Replaces numpyro.optim.Adam(lr) inside svi.update (vae.py:165,212): b1, b2, eps as given;
+ * step t counts from 1.  In place on params, m, v.                                                */
+int gpvae_adam(void *stream, int dtype, int64_t count, void *params, const void *grads, void *m,
+               void *v, int64_t t, double lr, double b1, double b2, double eps);
+
+/* ---- a11: decoder forward / VJP for MCMC chains ----------------------------------------------------
+ * Replaces decoder(decoder_params, z) of VAEInference.regression (inference.py:246) batched over
+ * `chains`, and the reverse-mode product NUTS needs.  dec_params: the decoder tail of the flat
+ * layout above: V1 c1 V2 c2 V3 c3.  Z: [chains, z], F: [chains, n].
+ * vjp: given dF [chains, n] returns dZ [chains, z] (recomputes activations; no saved state).      */
+int64_t gpvae_decoder_workspace_bytes(int dtype, int64_t chains, int64_t n, int h0, int h1, int z);
+int gpvae_decoder_fwd(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
+                      const void *dec_params, const void *Z, void *F, void *work);
+int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
+                      const void *dec_params, const void *Z, const void *dF, void *dZ, void *work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPVAE_H */
