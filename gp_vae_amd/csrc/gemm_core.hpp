@@ -121,7 +121,9 @@ template <typename T> static inline bool kc_vec_ok(const void *base, int64_t ld)
 }
 
 // ---- loader: source contiguous along the tile's row index:  element(r, k) = base[k*ld + r] --------
-template <typename T, int ROWS, int BK>
+// (the B operand of a row-major [K][N] matrix, or the A operand of a transposed product).
+// ONES: row index `ones_row` reads 1 for every k — appends a bias/column-sum row to a product.
+template <typename T, int ROWS, int BK, bool ONES = false>
 struct LoaderMC {
   static constexpr int VEC = VecT<T>::N;
   static constexpr int VPK = ROWS / VEC;  // vectors per k-row
@@ -130,25 +132,37 @@ struct LoaderMC {
   using V = typename VecT<T>::type;
   T regs[NV][VEC];
 
-  // rows [r0, r0+ROWS) clipped to < rend; k in [k0, k0+BK) clipped to [kbeg, kend)
+  // rows [r0, r0+ROWS) clipped to < rend; k in [k0, k0+BK) clipped to [kbeg, kend).
+  // vec (uniform): base and ld are 16-byte aligned, so a whole in-range vector can be one load.
   __device__ __forceinline__ void load(const T *base, int64_t ld, int64_t r0, int64_t rend,
-                                       int64_t k0, int64_t kbeg, int64_t kend, int tid) {
+                                       int64_t k0, int64_t kbeg, int64_t kend, bool vec, int tid,
+                                       int64_t ones_row = -1) {
+    const bool interior = vec && k0 >= kbeg && k0 + BK <= kend && r0 + ROWS <= rend &&
+                          (r0 % VEC) == 0;  // wave-uniform
+    if (interior) {
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int v = tid + p * NTHREADS;
-      const int kk = v / VPK;
-      const int64_t r = r0 + (v % VPK) * VEC;
-      const int64_t k = k0 + kk;
-      const bool kin = (EXACT || kk < BK) && k >= kbeg && k < kend;
-      const T *src = base + k * ld + r;
-      if (kin && r + VEC <= rend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-        const V t = *reinterpret_cast<const V *>(src);
+      for (int p = 0; p < NV; ++p) {
+        const int v = tid + p * NTHREADS;
+        const int kk = EXACT ? v / VPK : (v / VPK < BK ? v / VPK : BK - 1);
+        const V t = *reinterpret_cast<const V *>(base + (k0 + kk) * ld + r0 + (v % VPK) * VEC);
         const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) regs[p][e] = tp[e];
-      } else {
+      }
+    } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) regs[p][e] = (kin && r + e < rend) ? src[e] : T(0);
+      for (int p = 0; p < NV; ++p) {
+        const int v = tid + p * NTHREADS;
+        const int kk = v / VPK;
+        const int64_t r = r0 + (v % VPK) * VEC;
+        const int64_t k = k0 + kk;
+        const bool kin = (EXACT || kk < BK) && k >= kbeg && k < kend;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const bool in = kin && r + e < rend;
+          regs[p][e] = in ? base[in ? k * ld + r + e : 0] : T(0);
+          if (ONES && kin && r + e == ones_row) regs[p][e] = T(1);
+        }
       }
     }
   }

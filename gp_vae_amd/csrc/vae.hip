@@ -1,0 +1,678 @@
+// vae.hip — VAE encoder/decoder, one-particle ELBO forward + backward, Adam, chain decoder
+// (SURVEY.md §8 rows a5, a6, a7, a11).
+//
+// Replaces, operation for operation:
+//   stax encoder/decoder       /root/reference/src/model/vae.py:72-96
+//   vae_model / vae_guide      vae.py:98-137 under Trace_ELBO() (vae.py:213-218): loss = -ELBO,
+//                              summed over batch and dims, obs noise 0.1 (vae.py:117)
+//   optim.Adam                 vae.py:212 (numpyro/jax Adam: b1 .9, b2 .999, eps 1e-8)
+//   decoder(params, z)         src/model/inference.py:246
+//
+// Structure of one ELBO evaluation (B samples of length n; h0,h1,z small):
+//   [n-sized products on MFMA, split over K where the output is small, partial sums by float atomics]
+//     A1  += Y  W1                 (B x h0, K = n)          gemm<KC,MC>   reads Y once
+//     DF   = (D2 V3 + c3 - Y)/s^2  (B x n,  K = h0)         gemm<KC,MC>   + the data term of the loss
+//     dV3|dc3 += [D2|1]^T DF       ((h0+1) x n, K = B)      gemm<MC,MC>
+//     dD2 += DF V3^T               (B x h0, K = n)          gemm<KC,KC>
+//     dW1|db1 += [Y|1]^T dA1       ((n+1) x h0, K = B)      gemm<MC,MC>
+//   [everything between, per block of 16 samples, in LDS on the vector ALU]
+//     vae_mid_fwd: bias+relu, h0->h1->(mu, log sd), reparametrise, z->h1->h0; latent loss terms
+//     vae_mid_bwd: the same chain backwards; small weight gradients by atomics
+// Y is read three times (A1, DF, dW1) and DF twice; bound: HBM for the n-sized products.
+#include <algorithm>
+#include <cmath>
+#include "gemm_core.hpp"
+
+namespace gpvae {
+
+// ---- generic tile product C (M x N) = A (M x K) B (K x N), 128 x 64 tiles, split K -------------------
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_BIAS = 2, EPI_DF = 3 };
+
+template <typename T> struct GemmArgs {
+  const T *A;
+  int64_t lda;
+  const T *B;
+  int64_t ldb;
+  T *C;
+  int64_t ldc;
+  int64_t M, N, K;
+  int64_t kchunk;       // k range per blockIdx.z
+  int64_t a_ones_row;   // AKC == false: A row index that reads as ones (-1: none)
+  const T *bias;        // EPI_BIAS / EPI_DF: per column
+  const T *Yref;        // EPI_DF: data, ld = ldy
+  int64_t ldy;
+  T inv_var;            // EPI_DF: 1/obs_sigma^2
+  T *loss;              // EPI_DF: += 0.5 * sum diff^2 * inv_var
+  int vec_a, vec_b;
+};
+
+constexpr int GBM = 128, GBN = 64, GBK = 16;
+
+template <typename T, bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
+  using M = Mfma<T>;
+  constexpr int FM = 32 / M::TM;  // wave tile 32 x 64
+  constexpr int FN = 64 / M::TM;
+  constexpr int LDA = GBM + LdsPad<T>::V, LDB = GBN + LdsPad<T>::V;
+  __shared__ __align__(16) T As[GBK * LDA];
+  __shared__ __align__(16) T Bs[GBK * LDB];
+  __shared__ T red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * GBM, n0 = (int64_t)blockIdx.y * GBN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
+  const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  const int64_t Mrows = g.M;  // includes the ones row when present
+
+  LoaderKC<T, GBM, GBK> lak;
+  LoaderMC<T, GBM, GBK, true> lam;
+  LoaderKC<T, GBN, GBK> lbk;
+  LoaderMC<T, GBN, GBK> lbm;
+  if constexpr (AKC)
+    lak.init([&](int s, int64_t &rg) -> const T * { rg = m0 + s; return (m0 + s < Mrows) ? g.A + (m0 + s) * g.lda : nullptr; }, g.A, tid);
+  if constexpr (BKC)
+    lbk.init([&](int s, int64_t &rg) -> const T * { rg = n0 + s; return (n0 + s < g.N) ? g.B + (n0 + s) * g.ldb : nullptr; }, g.B, tid);
+  const int64_t a_rend = (g.a_ones_row >= 0) ? g.a_ones_row : Mrows;
+
+  auto load_tiles = [&](int64_t k0) {
+    if constexpr (AKC) lak.load(k0, kbeg, kend, g.vec_a, tid);
+    else lam.load(g.A, g.lda, m0, a_rend, k0, kbeg, kend, g.vec_a, tid, g.a_ones_row);
+    if constexpr (BKC) lbk.load(k0, kbeg, kend, g.vec_b, tid);
+    else lbm.load(g.B, g.ldb, n0, g.N, k0, kbeg, kend, g.vec_b, tid);
+  };
+  auto store_tiles = [&]() {
+    if constexpr (AKC) lak.template store<LDA>(As, tid);
+    else lam.template store<LDA>(As, tid);
+    if constexpr (BKC) lbk.template store<LDB>(Bs, tid);
+    else lbm.template store<LDB>(Bs, tid);
+  };
+
+  typename M::acc_t acc[FM][FN];
+  zero_acc<T, FM, FN>(acc);
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    store_tiles();
+    __syncthreads();
+    for (int64_t k = kbeg; k < kend; k += GBK) {
+      const bool more = k + GBK < kend;
+      if (more) load_tiles(k + GBK);
+      mma_ktile<T, FM, FN, GBK, LDA, LDB>(As, Bs, wave * 32, 0, lane, acc);
+      __syncthreads();
+      if (more) {
+        store_tiles();
+        __syncthreads();
+      }
+    }
+  }
+
+  T lsum = T(0);
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      const int64_t row = m0 + wave * 32 + fm * M::TM + M::row(lane, r);
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int64_t col = n0 + fn * M::TM + M::col(lane);
+        const bool in = row < Mrows && col < g.N;
+        const T v = acc[fm][fn][r];
+        if constexpr (EPI == EPI_STORE) {
+          if (in) g.C[row * g.ldc + col] = v;
+        } else if constexpr (EPI == EPI_ATOMIC) {
+          if (in) atomicAdd(&g.C[row * g.ldc + col], v);
+        } else if constexpr (EPI == EPI_BIAS) {
+          if (in) g.C[row * g.ldc + col] = v + g.bias[col];
+        } else {
+          const T y = g.Yref[in ? row * g.ldy + col : 0];
+          const T b = g.bias[in ? col : 0];
+          const T diff = in ? (v + b - y) : T(0);
+          lsum += diff * diff;
+          if (in) g.C[row * g.ldc + col] = diff * g.inv_var;
+        }
+      }
+    }
+  if constexpr (EPI == EPI_DF) {
+    lsum = wave_sum<T>(lsum);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) atomicAdd(g.loss, T(0.5) * g.inv_var * (red[0] + red[1] + red[2] + red[3]));
+  }
+}
+
+template <typename T, bool AKC, bool BKC, int EPI>
+static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
+  if (g.M <= 0 || g.N <= 0) return;
+  if (splitk < 1) splitk = 1;
+  int64_t kchunk = round_up(cdiv(g.K, splitk), GBK);
+  if (kchunk < GBK) kchunk = GBK;
+  g.kchunk = kchunk;
+  const int64_t nz = g.K > 0 ? cdiv(g.K, kchunk) : 1;
+  dim3 grid((unsigned)cdiv(g.M, GBM), (unsigned)cdiv(g.N, GBN), (unsigned)nz);
+  hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI>), grid, dim3(NTHREADS), 0, st, g);
+}
+
+template <typename T> static inline bool mc_vec_ok(const void *base, int64_t ld) {
+  return aligned16(base) && (ld % VecT<T>::N) == 0;
+}
+
+// ---- per-sample-block dense layers on the vector ALU ----------------------------------------------
+constexpr int RB = 16;  // samples per workgroup in the mid kernels
+
+// out[r][j] = bias[j] + sum_k in[r][k] W[k*N + j]   (r < RB); in/out are LDS, W/bias global
+template <typename T>
+__device__ __forceinline__ void dense_fwd(const T *in, int K, const T *__restrict__ W,
+                                          const T *__restrict__ bias, int N, T *out, int tid) {
+  for (int idx = tid; idx < RB * N; idx += NTHREADS) {
+    const int r = idx / N, j = idx % N;
+    T a = bias[j];
+    for (int k = 0; k < K; ++k) a += in[r * K + k] * W[(int64_t)k * N + j];
+    out[r * N + j] = a;
+  }
+}
+// out[r][k] = sum_j d[r][j] W[k*N + j]   (input gradient of a dense layer)
+template <typename T>
+__device__ __forceinline__ void dense_bwd_in(const T *d, int N, const T *__restrict__ W, int K,
+                                             T *out, int tid, bool accumulate = false) {
+  for (int idx = tid; idx < RB * K; idx += NTHREADS) {
+    const int r = idx / K, k = idx % K;
+    T a = accumulate ? out[r * K + k] : T(0);
+    for (int j = 0; j < N; ++j) a += d[r * N + j] * W[(int64_t)k * N + j];
+    out[r * K + k] = a;
+  }
+}
+// dW[k*N + j] += sum_r in[r][k] d[r][j];  db[j] += sum_r d[r][j]   (atomics across workgroups)
+template <typename T>
+__device__ __forceinline__ void dense_bwd_w(const T *in, int K, const T *d, int N, T *dW, T *db,
+                                            int rows, int tid) {
+  for (int idx = tid; idx < (K + 1) * N; idx += NTHREADS) {
+    const int k = idx / N, j = idx % N;
+    T a = T(0);
+    if (k < K) {
+      for (int r = 0; r < rows; ++r) a += in[r * K + k] * d[r * N + j];
+      atomicAdd(&dW[(int64_t)k * N + j], a);
+    } else {
+      for (int r = 0; r < rows; ++r) a += d[r * N + j];
+      atomicAdd(&db[j], a);
+    }
+  }
+}
+
+template <typename T> struct VaeDims {
+  int64_t B, n;
+  int h0, h1, z;
+};
+
+// flat parameter layout (include/gpvae.h)
+template <typename T> struct VaeParams {
+  const T *W1, *b1, *W2, *b2, *Wmu, *bmu, *Wsd, *bsd, *V1, *c1, *V2, *c2, *V3, *c3;
+  __host__ __device__ VaeParams(const T *p, int64_t n, int h0, int h1, int z) {
+    W1 = p;            b1 = W1 + n * h0;
+    W2 = b1 + h0;      b2 = W2 + (int64_t)h0 * h1;
+    Wmu = b2 + h1;     bmu = Wmu + (int64_t)h1 * z;
+    Wsd = bmu + z;     bsd = Wsd + (int64_t)h1 * z;
+    V1 = bsd + z;      c1 = V1 + (int64_t)z * h1;
+    V2 = c1 + h1;      c2 = V2 + (int64_t)h1 * h0;
+    V3 = c2 + h0;      c3 = V3 + (int64_t)h0 * n;
+  }
+};
+static inline int64_t vae_param_count(int64_t n, int h0, int h1, int z) {
+  return n * h0 + h0 + (int64_t)h0 * h1 + h1 + 2 * ((int64_t)h1 * z + z) + (int64_t)z * h1 + h1 +
+         (int64_t)h1 * h0 + h0 + (int64_t)h0 * n + n;
+}
+
+// workspace carve-up (elements of T)
+template <typename T> struct VaeWork {
+  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *DF;
+  static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
+    return B * (3 * (int64_t)h0 + 2 * (int64_t)h1 + 2 * (int64_t)z + h0) + B * n + 64;
+  }
+  __host__ VaeWork(T *w, int64_t B, int64_t n, int h0, int h1, int z) {
+    H1 = w;            H2 = H1 + B * h0;   SD = H2 + B * h1;   Z = SD + B * z;
+    D1 = Z + B * z;    D2 = D1 + B * h1;   dD2 = D2 + B * h0;  dA1 = dD2 + B * h0;
+    DF = dA1 + B * h0;
+    DF = (T *)(((uintptr_t)DF + 15) & ~(uintptr_t)15);
+  }
+};
+
+// encoder tail + reparametrisation + decoder head, RB samples per workgroup.
+// H1 holds Y W1 on entry (no bias) and relu(Y W1 + b1) on exit.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, const T *params,
+                                                               const T *eps, T *H1, T *H2, T *SD,
+                                                               T *Z, T *D1, T *D2, T *loss,
+                                                               T loss_const) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *bufA = reinterpret_cast<T *>(smem_raw);  // [RB][max dim]
+  const int mx = max(d.h0, max(d.h1, d.z));
+  T *bufB = bufA + RB * mx;
+  T *bufC = bufB + RB * mx;
+  __shared__ T red[4];
+  const VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
+  const int tid = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * RB;
+  const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
+  const int h0 = d.h0, h1 = d.h1, z = d.z;
+
+  // H1 = relu(A1 + b1)
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const int r = idx / h0, j = idx % h0;
+    T v = T(0);
+    if (r < rows) {
+      v = H1[(s0 + r) * h0 + j] + P.b1[j];
+      v = v > T(0) ? v : T(0);
+      H1[(s0 + r) * h0 + j] = v;
+    }
+    bufA[idx] = v;
+  }
+  __syncthreads();
+  dense_fwd<T>(bufA, h0, P.W2, P.b2, h1, bufB, tid);  // A2
+  __syncthreads();
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
+    const int r = idx / h1;
+    const T v = bufB[idx] > T(0) ? bufB[idx] : T(0);
+    bufB[idx] = v;
+    if (r < rows) H2[(s0 + r) * h1 + idx % h1] = v;
+  }
+  __syncthreads();
+  dense_fwd<T>(bufB, h1, P.Wmu, P.bmu, z, bufA, tid);  // mu
+  dense_fwd<T>(bufB, h1, P.Wsd, P.bsd, z, bufC, tid);  // log sd
+  __syncthreads();
+  T lsum = T(0);
+  for (int idx = tid; idx < RB * z; idx += NTHREADS) {
+    const int r = idx / z, j = idx % z;
+    T zz = T(0);
+    if (r < rows) {
+      const T e = eps[(s0 + r) * z + j];
+      const T ls = bufC[idx];
+      const T sd = dexp<T>(ls);  // stax.Exp head = std (vae.py:83)
+      zz = bufA[idx] + sd * e;   // z ~ Normal(z_loc, z_std)  (vae.py:135)
+      SD[(s0 + r) * z + j] = sd;
+      Z[(s0 + r) * z + j] = zz;
+      // -(log p(z) - log q(z)) = 0.5 z^2 - 0.5 eps^2 - log sd   (the 0.5 log 2pi terms cancel)
+      lsum += T(0.5) * zz * zz - T(0.5) * e * e - ls;
+    }
+    bufB[idx] = zz;  // reuse bufB as Z (h1 >= ... not assumed: RB*z <= RB*mx)
+  }
+  __syncthreads();
+  dense_fwd<T>(bufB, z, P.V1, P.c1, h1, bufA, tid);  // G1
+  __syncthreads();
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
+    const int r = idx / h1;
+    const T v = bufA[idx] > T(0) ? bufA[idx] : T(0);
+    bufA[idx] = v;
+    if (r < rows) D1[(s0 + r) * h1 + idx % h1] = v;
+  }
+  __syncthreads();
+  dense_fwd<T>(bufA, h1, P.V2, P.c2, h0, bufC, tid);  // G2
+  __syncthreads();
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const int r = idx / h0;
+    const T v = bufC[idx] > T(0) ? bufC[idx] : T(0);
+    if (r < rows) D2[(s0 + r) * h0 + idx % h0] = v;
+  }
+  if (loss != nullptr) {
+    lsum = wave_sum<T>(lsum);
+    if ((tid & 63) == 0) red[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0)
+      atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + (blockIdx.x == 0 ? loss_const : T(0)));
+  }
+}
+
+// the same chain backwards.  dD2 holds DF V3^T on entry; dA1 (gradient at Y W1 + b1) on exit.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, const T *params,
+                                                               T *grads, const T *eps,
+                                                               const T *H1, const T *H2,
+                                                               const T *SD, const T *Z,
+                                                               const T *D1, const T *D2,
+                                                               const T *dD2, T *dA1) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int mx = max(d.h0, max(d.h1, d.z));
+  T *act = reinterpret_cast<T *>(smem_raw);  // activations of the layer input
+  T *gA = act + RB * mx;                     // gradient buffers
+  T *gB = gA + RB * mx;
+  T *gC = gB + RB * mx;
+  const VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
+  const VaeParams<T> G(grads, d.n, d.h0, d.h1, d.z);  // same layout; const-cast below
+  const int tid = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * RB;
+  const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
+  const int h0 = d.h0, h1 = d.h1, z = d.z;
+  auto ld = [&](const T *src, int64_t r, int w, int j) { return r < rows ? src[(s0 + r) * w + j] : T(0); };
+
+  // dG2 = dD2 * (D2 > 0);  act = D1
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const int r = idx / h0, j = idx % h0;
+    gA[idx] = (ld(D2, r, h0, j) > T(0)) ? ld(dD2, r, h0, j) : T(0);
+  }
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) act[idx] = ld(D1, idx / h1, h1, idx % h1);
+  __syncthreads();
+  dense_bwd_w<T>(act, h1, gA, h0, (T *)G.V2, (T *)G.c2, rows, tid);
+  dense_bwd_in<T>(gA, h0, P.V2, h1, gB, tid);  // dD1
+  __syncthreads();
+  // dG1 = dD1 * (D1 > 0);  act = Z
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) gB[idx] = (act[idx] > T(0)) ? gB[idx] : T(0);
+  __syncthreads();
+  for (int idx = tid; idx < RB * z; idx += NTHREADS) act[idx] = ld(Z, idx / z, z, idx % z);
+  __syncthreads();
+  dense_bwd_w<T>(act, z, gB, h1, (T *)G.V1, (T *)G.c1, rows, tid);
+  dense_bwd_in<T>(gB, h1, P.V1, z, gA, tid);  // dZ (decoder part)
+  __syncthreads();
+  // dmu = dZ + z ; dls = dZ * eps * sd - 1   -> gA = dmu, gC = dls ;  act = H2
+  for (int idx = tid; idx < RB * z; idx += NTHREADS) {
+    const int r = idx / z, j = idx % z;
+    const T dz = (r < rows) ? gA[idx] + act[idx] : T(0);
+    gA[idx] = dz;
+    gC[idx] = (r < rows) ? dz * ld(eps, r, z, j) * ld(SD, r, z, j) - T(1) : T(0);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) act[idx] = ld(H2, idx / h1, h1, idx % h1);
+  __syncthreads();
+  dense_bwd_w<T>(act, h1, gA, z, (T *)G.Wmu, (T *)G.bmu, rows, tid);
+  dense_bwd_w<T>(act, h1, gC, z, (T *)G.Wsd, (T *)G.bsd, rows, tid);
+  dense_bwd_in<T>(gA, z, P.Wmu, h1, gB, tid);
+  __syncthreads();
+  dense_bwd_in<T>(gC, z, P.Wsd, h1, gB, tid, true);  // dH2
+  __syncthreads();
+  // dA2 = dH2 * (H2 > 0);  act = H1
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) gB[idx] = (act[idx] > T(0)) ? gB[idx] : T(0);
+  __syncthreads();
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) act[idx] = ld(H1, idx / h0, h0, idx % h0);
+  __syncthreads();
+  dense_bwd_w<T>(act, h0, gB, h1, (T *)G.W2, (T *)G.b2, rows, tid);
+  dense_bwd_in<T>(gB, h1, P.W2, h0, gA, tid);  // dH1
+  __syncthreads();
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const int r = idx / h0, j = idx % h0;
+    if (r < rows) dA1[(s0 + r) * h0 + j] = (act[idx] > T(0)) ? gA[idx] : T(0);
+  }
+}
+
+// decoder head only (chains): Z -> D1 -> D2 (a11 forward), and its reverse (a11 VJP)
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, const T *dec_params,
+                                                               const T *Zin, T *D1, T *D2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int mx = max(d.h0, max(d.h1, d.z));
+  T *bufA = reinterpret_cast<T *>(smem_raw);
+  T *bufB = bufA + RB * mx;
+  const int h0 = d.h0, h1 = d.h1, z = d.z;
+  const T *V1 = dec_params, *c1 = V1 + (int64_t)z * h1, *V2 = c1 + h1, *c2 = V2 + (int64_t)h1 * h0;
+  const int tid = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * RB;
+  const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
+  for (int idx = tid; idx < RB * z; idx += NTHREADS)
+    bufA[idx] = (idx / z < rows) ? Zin[(s0 + idx / z) * z + idx % z] : T(0);
+  __syncthreads();
+  dense_fwd<T>(bufA, z, V1, c1, h1, bufB, tid);
+  __syncthreads();
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
+    const T v = bufB[idx] > T(0) ? bufB[idx] : T(0);
+    bufB[idx] = v;
+    if (idx / h1 < rows) D1[(s0 + idx / h1) * h1 + idx % h1] = v;
+  }
+  __syncthreads();
+  dense_fwd<T>(bufB, h1, V2, c2, h0, bufA, tid);
+  __syncthreads();
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const T v = bufA[idx] > T(0) ? bufA[idx] : T(0);
+    if (idx / h0 < rows) D2[(s0 + idx / h0) * h0 + idx % h0] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void dec_mid_bwd_kernel(VaeDims<T> d, const T *dec_params,
+                                                               const T *D1, const T *D2,
+                                                               const T *dD2, T *dZ) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int mx = max(d.h0, max(d.h1, d.z));
+  T *gA = reinterpret_cast<T *>(smem_raw);
+  T *gB = gA + RB * mx;
+  const int h0 = d.h0, h1 = d.h1, z = d.z;
+  const T *V1 = dec_params, *c1 = V1 + (int64_t)z * h1, *V2 = c1 + h1;
+  const int tid = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * RB;
+  const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
+  for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
+    const int r = idx / h0, j = idx % h0;
+    gA[idx] = (r < rows && D2[(s0 + r) * h0 + j] > T(0)) ? dD2[(s0 + r) * h0 + j] : T(0);
+  }
+  __syncthreads();
+  dense_bwd_in<T>(gA, h0, V2, h1, gB, tid);
+  __syncthreads();
+  for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
+    const int r = idx / h1, j = idx % h1;
+    gB[idx] = (r < rows && D1[(s0 + r) * h1 + j] > T(0)) ? gB[idx] : T(0);
+  }
+  __syncthreads();
+  dense_bwd_in<T>(gB, h1, V1, z, gA, tid);
+  __syncthreads();
+  for (int idx = tid; idx < RB * z; idx += NTHREADS)
+    if (idx / z < rows) dZ[(s0 + idx / z) * z + idx % z] = gA[idx];
+}
+
+// ---- Adam (jax.experimental.optimizers.adam, as numpyro.optim.Adam wraps it) ------------------------
+//   m = (1-b1) g + b1 m ; v = (1-b2) g^2 + b2 v ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+template <typename T>
+__global__ void adam_kernel(int64_t count, T *p, const T *g, T *m, T *v, T lr, T b1, T b2, T eps,
+                            T c1, T c2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const T gi = g[i];
+    const T mi = (T(1) - b1) * gi + b1 * m[i];
+    const T vi = (T(1) - b2) * gi * gi + b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    const T mhat = mi / c1, vhat = vi / c2;
+    p[i] = p[i] - lr * mhat / (dsqrt<T>(vhat) + eps);
+  }
+}
+
+static inline int pick_splitk(int64_t tiles, int64_t K) {
+  int s = (int)(1024 / (tiles > 0 ? tiles : 1));
+  if (s < 1) s = 1;
+  const int64_t maxs = cdiv(K, 4 * GBK);  // at least 4 k-tiles per slice
+  if (s > maxs) s = (int)(maxs > 0 ? maxs : 1);
+  return s;
+}
+
+template <typename T>
+static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, int z,
+                        const void *params_v, const void *Y_v, int64_t ldy, const void *eps_v,
+                        double obs_sigma, void *loss_v, void *grads_v, void *work_v) {
+  const T *params = (const T *)params_v, *Y = (const T *)Y_v, *eps = (const T *)eps_v;
+  T *loss = (T *)loss_v, *grads = (T *)grads_v;
+  VaeWork<T> W((T *)work_v, B, n, h0, h1, z);
+  VaeParams<T> P(params, n, h0, h1, z);
+  VaeDims<T> dims{B, n, h0, h1, z};
+  const int mx = std::max(h0, std::max(h1, z));
+  const size_t shm_f = 3 * (size_t)RB * mx * sizeof(T), shm_b = 4 * (size_t)RB * mx * sizeof(T);
+  const unsigned nblk = (unsigned)cdiv(B, RB);
+  const T inv_var = (T)(1.0 / (obs_sigma * obs_sigma));
+  // constant of the data term: B*n*(log sigma + 0.5 log 2pi)
+  const T loss_const = (T)((double)B * (double)n * (log(obs_sigma) + 0.9189385332046727));
+
+  (void)hipMemsetAsync(loss, 0, sizeof(T), st);
+  (void)hipMemsetAsync(W.H1, 0, sizeof(T) * B * h0, st);
+  {  // A1 += Y W1
+    GemmArgs<T> g{};
+    g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.H1; g.ldc = h0;
+    g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
+    g.vec_a = kc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(P.W1, h0);
+    launch_gemm<T, true, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
+  }
+  hipLaunchKernelGGL((vae_mid_fwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_f, st, dims, params,
+                     eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss, loss_const);
+  {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
+    GemmArgs<T> g{};
+    g.A = W.D2; g.lda = h0; g.B = P.V3; g.ldb = n; g.C = W.DF; g.ldc = n;
+    g.M = B; g.N = n; g.K = h0; g.a_ones_row = -1;
+    g.bias = P.c3; g.Yref = Y; g.ldy = ldy; g.inv_var = inv_var; g.loss = loss;
+    g.vec_a = kc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(P.V3, n);
+    launch_gemm<T, true, false, EPI_DF>(st, g, 1);
+  }
+  if (grads != nullptr) {
+    VaeParams<T> G(grads, n, h0, h1, z);
+    (void)hipMemsetAsync(grads, 0, sizeof(T) * vae_param_count(n, h0, h1, z), st);
+    (void)hipMemsetAsync(W.dD2, 0, sizeof(T) * B * h0, st);
+    {  // [dV3; dc3] += [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
+      GemmArgs<T> g{};
+      g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
+      g.M = h0 + 1; g.N = n; g.K = B; g.a_ones_row = h0;
+      g.vec_a = mc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(W.DF, n);
+      launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
+    }
+    {  // dD2 += DF V3^T
+      GemmArgs<T> g{};
+      g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.dD2; g.ldc = h0;
+      g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
+      g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
+      launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
+    }
+    hipLaunchKernelGGL((vae_mid_bwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_b, st, dims,
+                       params, grads, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, W.dD2, W.dA1);
+    {  // [dW1; db1] += [Y | 1]^T dA1        ((n+1) x h0; W1 and b1 are adjacent in the layout)
+      GemmArgs<T> g{};
+      g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = (T *)G.W1; g.ldc = h0;
+      g.M = n + 1; g.N = h0; g.K = B; g.a_ones_row = n;
+      g.vec_a = mc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(W.dA1, h0);
+      launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(n + 1, GBM) * cdiv(h0, GBN), B));
+    }
+  }
+  GPVAE_CHECK_LAUNCH("gpvae_vae_elbo");
+  return 0;
+}
+
+template <typename T>
+static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, int h1, int z,
+                       const void *dec_v, const void *Z_v, const void *dF_v, void *out_v,
+                       void *work_v) {
+  const T *dec = (const T *)dec_v;
+  const T *V3 = dec + (int64_t)z * h1 + h1 + (int64_t)h1 * h0 + h0, *c3 = V3 + (int64_t)h0 * n;
+  T *D1 = (T *)work_v, *D2 = D1 + C * h1, *dD2 = D2 + C * h0;
+  VaeDims<T> dims{C, n, h0, h1, z};
+  const int mx = std::max(h0, std::max(h1, z));
+  const size_t shm = 2 * (size_t)RB * mx * sizeof(T);
+  const unsigned nblk = (unsigned)cdiv(C, RB);
+  hipLaunchKernelGGL((dec_mid_fwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm, st, dims, dec,
+                     (const T *)Z_v, D1, D2);
+  if (!vjp) {  // F = D2 V3 + c3
+    GemmArgs<T> g{};
+    g.A = D2; g.lda = h0; g.B = V3; g.ldb = n; g.C = (T *)out_v; g.ldc = n;
+    g.M = C; g.N = n; g.K = h0; g.a_ones_row = -1; g.bias = c3;
+    g.vec_a = kc_vec_ok<T>(D2, h0); g.vec_b = mc_vec_ok<T>(V3, n);
+    launch_gemm<T, true, false, EPI_BIAS>(st, g, 1);
+  } else {  // dD2 = dF V3^T, then back through the head
+    GemmArgs<T> g{};
+    g.A = (const T *)dF_v; g.lda = n; g.B = V3; g.ldb = n; g.C = dD2; g.ldc = h0;
+    g.M = C; g.N = h0; g.K = n; g.a_ones_row = -1;
+    g.vec_a = kc_vec_ok<T>(dF_v, n); g.vec_b = kc_vec_ok<T>(V3, n);
+    (void)hipMemsetAsync(dD2, 0, sizeof(T) * C * h0, st);
+    launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(C, GBM) * cdiv(h0, GBN), n));
+    hipLaunchKernelGGL((dec_mid_bwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm, st, dims, dec, D1,
+                       D2, dD2, (T *)out_v);
+  }
+  GPVAE_CHECK_LAUNCH(vjp ? "gpvae_decoder_vjp" : "gpvae_decoder_fwd");
+  return 0;
+}
+
+}  // namespace gpvae
+
+using namespace gpvae;
+
+static int check_dims(const char *fn, int dtype, int64_t B, int64_t n, int h0, int h1, int z) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "%s: bad dtype %d", fn, dtype);
+  GPVAE_REQUIRE(B >= 0, 3, "%s: batch < 0", fn);
+  GPVAE_REQUIRE(n >= 1, 4, "%s: n < 1", fn);
+  GPVAE_REQUIRE(h0 >= 1 && h0 <= 1024, 5, "%s: h0 out of range [1,1024]", fn);
+  GPVAE_REQUIRE(h1 >= 1 && h1 <= 1024, 6, "%s: h1 out of range [1,1024]", fn);
+  GPVAE_REQUIRE(z >= 1 && z <= 1024, 7, "%s: z out of range [1,1024]", fn);
+  return 0;
+}
+
+extern "C" int64_t gpvae_vae_param_count(int64_t n, int h0, int h1, int z) {
+  return vae_param_count(n, h0, h1, z);
+}
+
+extern "C" int64_t gpvae_vae_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1,
+                                             int z) {
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  return VaeWork<float>::elems(B, n, h0, h1, z) * es + 256;
+}
+
+extern "C" int gpvae_vae_elbo(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,
+                              const void *params, const void *Y, int64_t ldy, const void *eps_z,
+                              double obs_sigma, void *loss, void *grads, void *work) {
+  if (int rc = check_dims("gpvae_vae_elbo", dtype, B, n, h0, h1, z)) return rc;
+  GPVAE_REQUIRE(params, 8, "gpvae_vae_elbo: params is NULL");
+  GPVAE_REQUIRE(loss, 13, "gpvae_vae_elbo: loss is NULL");
+  GPVAE_REQUIRE(obs_sigma > 0, 12, "gpvae_vae_elbo: obs_sigma must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    (void)hipMemsetAsync(loss, 0, dtype == GPVAE_F64 ? 8 : 4, st);
+    if (grads) (void)hipMemsetAsync(grads, 0, (dtype == GPVAE_F64 ? 8 : 4) * vae_param_count(n, h0, h1, z), st);
+    return 0;
+  }
+  GPVAE_REQUIRE(Y, 9, "gpvae_vae_elbo: Y is NULL");
+  GPVAE_REQUIRE(ldy >= n, 10, "gpvae_vae_elbo: ldy < n");
+  GPVAE_REQUIRE(eps_z, 11, "gpvae_vae_elbo: eps_z is NULL");
+  GPVAE_REQUIRE(work, 15, "gpvae_vae_elbo: work is NULL");
+  GPVAE_REQUIRE(aligned16(work), 15, "gpvae_vae_elbo: work must be 16-byte aligned");
+  return dtype == GPVAE_F32
+             ? run_vae_elbo<float>(st, B, n, h0, h1, z, params, Y, ldy, eps_z, obs_sigma, loss, grads, work)
+             : run_vae_elbo<double>(st, B, n, h0, h1, z, params, Y, ldy, eps_z, obs_sigma, loss, grads, work);
+}
+
+extern "C" int gpvae_adam(void *stream, int dtype, int64_t count, void *params, const void *grads,
+                          void *m, void *v, int64_t t, double lr, double b1, double b2,
+                          double eps) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_adam: bad dtype %d", dtype);
+  GPVAE_REQUIRE(count >= 0, 3, "gpvae_adam: count < 0");
+  GPVAE_REQUIRE(t >= 1, 8, "gpvae_adam: step t counts from 1");
+  if (count == 0) return 0;
+  GPVAE_REQUIRE(params && grads && m && v, 4, "gpvae_adam: NULL pointer");
+  const double c1 = 1.0 - pow(b1, (double)t), c2 = 1.0 - pow(b2, (double)t);
+  int64_t blocks = cdiv(count, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((adam_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, count,
+                       (float *)params, (const float *)grads, (float *)m, (float *)v, (float)lr,
+                       (float)b1, (float)b2, (float)eps, (float)c1, (float)c2);
+  else
+    hipLaunchKernelGGL((adam_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, count,
+                       (double *)params, (const double *)grads, (double *)m, (double *)v, lr, b1,
+                       b2, eps, c1, c2);
+  GPVAE_CHECK_LAUNCH("gpvae_adam");
+  return 0;
+}
+
+extern "C" int64_t gpvae_decoder_workspace_bytes(int dtype, int64_t chains, int64_t n, int h0,
+                                                 int h1, int z) {
+  (void)n; (void)z;
+  return chains * ((int64_t)h1 + 2 * (int64_t)h0) * (dtype == GPVAE_F64 ? 8 : 4) + 256;
+}
+
+extern "C" int gpvae_decoder_fwd(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1,
+                                 int z, const void *dec_params, const void *Z, void *F,
+                                 void *work) {
+  if (int rc = check_dims("gpvae_decoder_fwd", dtype, chains, n, h0, h1, z)) return rc;
+  if (chains == 0) return 0;
+  GPVAE_REQUIRE(dec_params && Z && F && work, 8, "gpvae_decoder_fwd: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32
+             ? run_decoder<float>(st, false, chains, n, h0, h1, z, dec_params, Z, nullptr, F, work)
+             : run_decoder<double>(st, false, chains, n, h0, h1, z, dec_params, Z, nullptr, F, work);
+}
+
+extern "C" int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1,
+                                 int z, const void *dec_params, const void *Z, const void *dF,
+                                 void *dZ, void *work) {
+  if (int rc = check_dims("gpvae_decoder_vjp", dtype, chains, n, h0, h1, z)) return rc;
+  if (chains == 0) return 0;
+  GPVAE_REQUIRE(dec_params && Z && dF && dZ && work, 8, "gpvae_decoder_vjp: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32
+             ? run_decoder<float>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work)
+             : run_decoder<double>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work);
+}

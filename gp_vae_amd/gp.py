@@ -1,0 +1,152 @@
+"""GP prior — mirrors /root/reference/src/model/gp.py on top of libgpvae_hip.
+
+Same names, argument order and defaults as the reference (`exp_kernel2`, `agg_kernel_grid`, `GP`),
+with torch device tensors where the reference has jax arrays.  NumPyro is not a dependency: where
+the reference relies on `Predictive(gp.sample, num_samples=B)` to vectorise a NumPyro model,
+:class:`Predictive` below gives the same call shape and return dict.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import GpvaeError
+
+
+def _as_device(x, dtype=None):
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.as_tensor(np.asarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    elif not t.is_floating_point():
+        t = t.to(torch.float32)
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise GpvaeError("gp_vae_amd needs a HIP device (there is no CPU path)")
+        t = t.cuda()
+    return t
+
+
+def exp_kernel2(x, z, var, ls, jitter=1.0e-5):
+    """Squared-exponential Gram matrix (gp.py:44-81): var*exp(-0.5*(|x-z|/ls)^2), +jitter*I iff square."""
+    x = _as_device(x)
+    z = _as_device(z, x.dtype)
+    return ops.gram_se(x, z, var, ls, jitter)
+
+
+def _seed_of(rng_key):
+    """An int, a numpy Generator/SeedSequence-like or a 2-word key all reduce to one 64-bit seed."""
+    if rng_key is None:
+        return 0
+    if isinstance(rng_key, (int, np.integer)):
+        return int(rng_key) & (2 ** 63 - 1)
+    a = np.asarray(rng_key).astype(np.uint64).reshape(-1)
+    s = 0
+    for w in a:
+        s = (s * 0x9E3779B97F4A7C15 + int(w)) & (2 ** 63 - 1)
+    return s
+
+
+def agg_kernel_grid(rng_key, d, m, kernel, var, ls, grid1, grid2=None, jitter=1.0e-6):
+    """Cell-averaged kernel over a [0,1]^d grid (gp.py:85-127).
+
+    The Uniform(0,1) locations come from torch's generator seeded by `rng_key` (the reference's
+    threefry stream is not reproducible without JAX); `rng_key` may also be a ready-made tensor of
+    uniforms [n^d, m, d].  `jitter` keeps the literal behaviour: + jitter/m on every entry."""
+    if kernel is not exp_kernel2:
+        raise NotImplementedError("agg_kernel_grid is built for exp_kernel2 only")
+    if d not in (1, 2):
+        raise Warning("Function is only implemented for d=1,2")  # gp.py:117
+    grid1 = _as_device(grid1)
+    n = grid1.shape[0]  # gp.py:99 with the `shape()` typo fixed
+    if isinstance(rng_key, torch.Tensor) and rng_key.dim() == 3:
+        u = _as_device(rng_key, grid1.dtype)
+    else:
+        gen = torch.Generator(device=grid1.device)
+        gen.manual_seed(_seed_of(rng_key))
+        u = torch.rand((n ** d, m, d), generator=gen, device=grid1.device, dtype=grid1.dtype)
+    if d == 1:
+        pts = u / n + grid1[:, None, None]  # gp.py:107
+    else:
+        g2 = grid1 if grid2 is None else _as_device(grid2, grid1.dtype)
+        uu, vv = torch.meshgrid(grid1, g2, indexing="xy")  # jnp.meshgrid default     gp.py:112
+        org = torch.stack([uu.flatten(), vv.flatten()], dim=1)[:, None, :]  # gp.py:113
+        pts = u / n + org
+    return ops.gram_agg(pts, var, ls, jitter)
+
+
+def draw_hyper(rng, size=None):
+    """(ls, var, sigma) ~ InverseGamma(1,0.1), LogNormal(0,0.1), HalfNormal(0.1)  (gp.py:171-176)."""
+    ls = 0.1 / rng.gamma(1.0, size=size)
+    var = np.exp(0.1 * rng.standard_normal(size=size))
+    sigma = np.abs(0.1 * rng.standard_normal(size=size))
+    return ls, var, sigma
+
+
+class GP():
+    """GP prior with the reference's constructor (gp.py:141-156)."""
+
+    def __init__(self, kernel=exp_kernel2, jitter=1.0e-5, d=1):
+        self.kernel = kernel
+        self.jitter = jitter
+        self.d = d
+
+    def sample(self, x, y=None, ls=None, var=None, sigma=None, rng_key=None, num_samples=1):
+        """Draw from the GP (gp.py:159-194): k = kernel(x,x,var,ls,jitter); f ~ MVN(0,k);
+        y ~ Normal(f, sigma).  Hyper-parameters left None are drawn from their priors, one set PER
+        SAMPLE (what Predictive does to the NumPyro model).  Returns {'f','y'[, 'length','var',
+        'noise']} with a leading [num_samples] axis."""
+        x = _as_device(x)
+        n = x.shape[0]
+        seed = _seed_of(rng_key)
+        B = int(num_samples)
+        E = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=1)
+        E2 = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=2)
+        out = {}
+        if ls is not None and var is not None and sigma is not None:
+            K = self.kernel(x, x, var, ls, self.jitter)
+            ops.potrf_(K)
+            F, Y = ops.draw(K, E, E2, sigma, want_f=True)
+        else:
+            rng = np.random.default_rng(seed)
+            ls_s, var_s, sig_s = draw_hyper(rng, B)
+            if ls is not None:
+                ls_s = np.full(B, float(ls))
+            else:
+                out["length"] = torch.as_tensor(ls_s, dtype=x.dtype, device=x.device)
+            if var is not None:
+                var_s = np.full(B, float(var))
+            else:
+                out["var"] = torch.as_tensor(var_s, dtype=x.dtype, device=x.device)
+            if sigma is not None:
+                sig_s = np.full(B, float(sigma))
+            else:
+                out["noise"] = torch.as_tensor(sig_s, dtype=x.dtype, device=x.device)
+            if self.kernel is not exp_kernel2:
+                raise NotImplementedError("per-sample hyper-parameters need the built-in kernel")
+            Kb = ops.gram_se(x, x, torch.as_tensor(var_s, dtype=x.dtype, device=x.device),
+                             torch.as_tensor(ls_s, dtype=x.dtype, device=x.device), self.jitter)
+            Kb = Kb.reshape(B, n, n)
+            ops.potrf_(Kb)  # B distinct factors in one batched sweep
+            F = torch.empty((B, n), dtype=x.dtype, device=x.device)
+            Y = torch.empty((B, n), dtype=x.dtype, device=x.device)
+            for b in range(B):
+                f_b, y_b = ops.draw(Kb[b], E[b:b + 1], E2[b:b + 1], float(sig_s[b]), want_f=True)
+                F[b], Y[b] = f_b[0], y_b[0]
+        out["f"] = F
+        out["y"] = Y if y is None else _as_device(y, x.dtype).expand(B, n)
+        return out
+
+
+class Predictive():
+    """Call-compatible stand-in for numpyro.infer.Predictive(model, num_samples=...) applied to
+    GP.sample (vae.py:223, toy_examples.py:88): `Predictive(gp.sample, num_samples=B)(rng_key, x=x,
+    ls=..., var=..., sigma=...)` -> {'y': [B,n], 'f': [B,n], ...}."""
+
+    def __init__(self, model, num_samples):
+        self.model = model
+        self.num_samples = num_samples
+
+    def __call__(self, rng_key, *args, **kwargs):
+        return self.model(*args, rng_key=rng_key, num_samples=self.num_samples, **kwargs)

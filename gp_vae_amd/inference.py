@@ -1,0 +1,144 @@
+"""Inference drivers — mirror /root/reference/src/model/inference.py on top of libgpvae_hip.
+
+What is built natively here is the arithmetic NUTS and the kriging post-processing call on every
+evaluation:
+  * GPInference.gp_prediction            -> gpvae_krig_predict (one problem, any size)
+  * GPInference.gp_fit_from_samples      -> the vmap over posterior samples (inference.py:511-521),
+                                            sharded over ranks with no collective
+  * VAEInference.potential_and_grad      -> gpvae_decoder_fwd / gpvae_decoder_vjp batched over chains
+                                            (what NUTS asks of VAEInference.regression per leapfrog)
+The NUTS transition itself is NumPyro's (third party, not in the reference tree): `run_mcmc` raises
+unless numpyro is importable.  Plotting (inference.py:149-204) is out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import GpvaeError
+from .gp import _as_device, _seed_of, exp_kernel2
+from .parallel import shard
+from .vae import decoder_flat_from_list
+
+
+class Inference():
+    """Constructor and attributes of the reference base class (inference.py:35-59)."""
+
+    def __init__(self, d, x, y, obs_idx, mcmc_args, seed=0, ground_truth=None, grid=True,
+                 dtype=torch.float32):
+        self.d = d
+        self.x = _as_device(x, dtype)
+        self.y = _as_device(y, dtype)
+        self.obs_idx = torch.as_tensor(np.asarray(obs_idx), dtype=torch.long, device=self.x.device)
+        self.mcmc_args = mcmc_args
+        self.seed = seed
+        self.ground_truth = ground_truth
+        self.grid = grid
+        self.dtype = dtype
+        if grid:
+            self.n = int(round(self.x.shape[0] ** (1 / d)))  # inference.py:57
+        else:
+            self.n = self.x.shape[0]
+
+    def regression(self, y=None, obs_idx=None):
+        raise NotImplementedError  # inference.py:63-66
+
+    def run_mcmc(self, rng_key):
+        raise GpvaeError("run_mcmc drives numpyro.infer.NUTS, which is third-party code absent from "
+                         "this environment; use potential_and_grad / gp_prediction with your sampler")
+
+
+class GPInference(Inference):
+    """Kriging with a GP prior (inference.py:338-549)."""
+
+    def __init__(self, kernel, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if kernel is not exp_kernel2:
+            raise NotImplementedError("GPInference is built for exp_kernel2")
+        self.kernel = kernel
+
+    def _split(self):
+        n = self.x.shape[0]
+        mask = torch.ones(n, dtype=torch.bool, device=self.x.device)
+        mask[self.obs_idx] = False
+        test_idx = torch.nonzero(mask).reshape(-1)  # jnp.delete(x, obs_idx, axis=0)  inference.py:442
+        return self.x[self.obs_idx].contiguous(), self.x[test_idx].contiguous()
+
+    def gp_prediction(self, rng_key, x, y, var, ls, sigma, return_var=False):
+        """Posterior mean and one posterior sample at the unobserved locations (inference.py:427-460).
+        `rng_key` seeds the standard normals of the sample (Philox stream)."""
+        if x is not self.x:
+            self.x = _as_device(x, self.dtype)
+        y = _as_device(y, self.dtype)
+        x_obs, x_test = self._split()
+        xi = ops.randn((x_test.shape[0],), self.dtype, self.x.device, seed=_seed_of(rng_key),
+                       stream_id=0xC41)
+        mean, sample, var_out, info = ops.krig_predict(x_obs, x_test, y[self.obs_idx], var, ls,
+                                                       sigma, 1.0e-5, xi)
+        self.last_info = info
+        return (mean, sample, var_out) if return_var else (mean, sample)
+
+    def gp_fit_from_samples(self, rng_key, post_samples):
+        """The posterior-predictive sweep of gp_fit (inference.py:511-521): one gp_prediction per
+        posterior draw of (kernel_var, kernel_length, kernel_sigma).  With torch.distributed
+        initialised the draws are sharded round-robin over ranks; no data-path collective — each
+        rank returns its own rows (the host concatenates if it wants all of them)."""
+        var = np.asarray(post_samples["kernel_var"], dtype=np.float64)
+        ls = np.asarray(post_samples["kernel_length"], dtype=np.float64)
+        sig = np.asarray(post_samples["kernel_sigma"], dtype=np.float64)
+        mine = shard(var.shape[0])
+        base = _seed_of(rng_key)
+        means, preds = [], []
+        for s in mine:
+            m, p = self.gp_prediction(base + s, self.x, self.y, var[s], ls[s], sig[s])
+            means.append(m)
+            preds.append(p)
+        return torch.stack(means), torch.stack(preds)
+
+
+class VAEInference(Inference):
+    """MCMC with the trained decoder as prior (inference.py:208-254)."""
+
+    def __init__(self, decoder, decoder_params, z_dim, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.decoder = decoder
+        self.decoder_params = decoder_params
+        self.z_dim = z_dim
+        (V1, _), _, (V2, _), _, (V3, _) = decoder_params
+        self.h1, self.h0, self.n_out = V1.shape[1], V2.shape[1], V3.shape[1]
+        self.dec_flat = decoder_flat_from_list(decoder_params, self.dtype)
+
+    def predict(self, z):
+        """f = decoder(decoder_params, z) for a batch of latent vectors [chains, z_dim]."""
+        return ops.decoder_fwd(self.dec_flat, _as_device(z, self.dtype).reshape(-1, self.z_dim),
+                               self.n_out, self.h0, self.h1)
+
+    def potential_and_grad(self, z, log_sigma):
+        """Potential energy of VAEInference.regression (inference.py:243-254) in NumPyro's
+        unconstrained space, and its gradient, for a batch of chains.
+
+        sites: noise ~ HalfNormal(0.1) with sigma = exp(log_sigma); z ~ N(0, I);
+               y[obs] ~ Normal(decoder(z)[obs], sigma).
+        Returns (U [chains], dU/dz [chains, z_dim], dU/dlog_sigma [chains]).  The decoder forward and
+        its vector-Jacobian product are the HIP kernels; the O(chains * n_obs) tail is glue."""
+        z = _as_device(z, self.dtype).reshape(-1, self.z_dim).contiguous()
+        u = _as_device(log_sigma, self.dtype).reshape(-1)
+        sigma = torch.exp(u)
+        f = ops.decoder_fwd(self.dec_flat, z, self.n_out, self.h0, self.h1)
+        y_obs = self.y[self.obs_idx]
+        r = f[:, self.obs_idx] - y_obs[None, :]
+        n_obs = self.obs_idx.numel()
+        s0 = 0.1
+        half_log_2pi = 0.5 * math.log(2 * math.pi)
+        sq = (r * r).sum(1)
+        log_lik = -0.5 * sq / sigma ** 2 - n_obs * (u + half_log_2pi)
+        log_pz = (-0.5 * z * z).sum(1) - self.z_dim * half_log_2pi
+        log_ps = math.log(2.0) - half_log_2pi - math.log(s0) - 0.5 * (sigma / s0) ** 2 + u
+        U = -(log_lik + log_pz + log_ps)
+        dF = torch.zeros_like(f)
+        dF[:, self.obs_idx] = r / (sigma ** 2)[:, None]
+        dz = z + ops.decoder_vjp(self.dec_flat, z, dF, self.h0, self.h1)
+        du = (sigma / s0) ** 2 - 1.0 + n_obs - sq / sigma ** 2
+        return U, dz, du

@@ -91,9 +91,9 @@ def gram_agg(pts, var, ls, jitter=1.0e-6):
     n_cells, m, d = pts.shape
     K = torch.empty((n_cells, n_cells), dtype=pts.dtype, device=pts.device)
     lib = _lib.load()
-    check(lib.gpvae_gram_agg(_stream(), _dt(pts), d, n_cells, m, _p(pts), _p(scalar(var, pts)),
-                             _p(scalar(ls, pts)), float(jitter), _p(K), K.stride(0)),
-          "gpvae_gram_agg")
+    var_t, ls_t = scalar(var, pts), scalar(ls, pts)  # keep alive until the launch is enqueued
+    check(lib.gpvae_gram_agg(_stream(), _dt(pts), d, n_cells, m, _p(pts), _p(var_t), _p(ls_t),
+                             float(jitter), _p(K), K.stride(0)), "gpvae_gram_agg")
     return K
 
 
@@ -151,3 +151,101 @@ def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=No
     check(lib.gpvae_randn(_stream(), _dt(out), out.numel(), int(seed), int(stream_id), _p(out)),
           "gpvae_randn")
     return out
+
+
+# ---- a9 kriging ---------------------------------------------------------------------------------------
+def krig_predict(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi=None):
+    """(mean, sample, var) at x_test given observations; literal gp_prediction arithmetic.
+
+    Returns also the int32 info tensor of the factorisation."""
+    _dev(x_obs, x_test, y_obs, xi)
+    x_obs, x_test = _points(x_obs), _points(x_test)
+    n_obs, n_test, d = x_obs.shape[0], x_test.shape[0], x_obs.shape[1]
+    y_obs = y_obs.contiguous()
+    lib = _lib.load()
+    nbytes = lib.gpvae_krig_workspace_bytes(_dt(x_obs), n_obs, n_test)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=x_obs.device)
+    mean = torch.empty(n_test, dtype=x_obs.dtype, device=x_obs.device)
+    samp = torch.empty_like(mean)
+    vout = torch.empty_like(mean)
+    info = torch.empty(1, dtype=torch.int32, device=x_obs.device)
+    if xi is not None:
+        xi = xi.contiguous()
+    # named locals: a temporary's storage would be recycled for the next scalar before the launch
+    var_t, ls_t, sig_t = scalar(var, x_obs), scalar(ls, x_obs), scalar(sigma, x_obs)
+    check(lib.gpvae_krig_predict(_stream(), _dt(x_obs), d, n_obs, n_test, _p(x_obs), _p(x_test),
+                                 _p(y_obs), _p(var_t), _p(ls_t), _p(sig_t), float(jitter), _p(xi),
+                                 _p(mean), _p(samp), _p(vout), _p(info), _p(work)),
+          "gpvae_krig_predict")
+    return mean, samp, vout, info
+
+
+# ---- a5-a7, a11: VAE -----------------------------------------------------------------------------------
+def vae_param_count(n, h0, h1, z):
+    return int(_lib.load().gpvae_vae_param_count(n, h0, h1, z))
+
+
+class VaeWorkspace:
+    """Caller-owned scratch for vae_elbo at a fixed (B, n, h0, h1, z, dtype)."""
+
+    def __init__(self, B, n, h0, h1, z, dtype, device):
+        lib = _lib.load()
+        self.key = (B, n, h0, h1, z, dtype)
+        nbytes = lib.gpvae_vae_workspace_bytes(_DT[dtype], B, n, h0, h1, z)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def vae_elbo(params, Y, eps_z, dims, obs_sigma=0.1, grads=None, loss=None, work=None):
+    """loss = -ELBO(Y) (device scalar); if `grads` (flat like params) is given it is overwritten."""
+    _dev(params, Y, eps_z, grads)
+    h0, h1, z = dims
+    B, n = Y.shape
+    if Y.stride(1) != 1 or not eps_z.is_contiguous() or eps_z.shape != (B, z):
+        raise GpvaeError("vae_elbo: Y needs unit column stride, eps_z must be contiguous [B,z]")
+    if params.numel() != vae_param_count(n, h0, h1, z) or not params.is_contiguous():
+        raise GpvaeError("vae_elbo: params has the wrong length for (n,h0,h1,z)")
+    if work is None or work.key != (B, n, h0, h1, z, Y.dtype):
+        work = VaeWorkspace(B, n, h0, h1, z, Y.dtype, Y.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=Y.dtype, device=Y.device)
+    lib = _lib.load()
+    check(lib.gpvae_vae_elbo(_stream(), _dt(Y), B, n, h0, h1, z, _p(params), _p(Y), Y.stride(0),
+                             _p(eps_z), float(obs_sigma), _p(loss), _p(grads), _p(work.buf)),
+          "gpvae_vae_elbo")
+    return loss
+
+
+def adam_(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    _dev(params, grads, m, v)
+    lib = _lib.load()
+    check(lib.gpvae_adam(_stream(), _dt(params), params.numel(), _p(params), _p(grads), _p(m), _p(v),
+                         int(t), float(lr), float(b1), float(b2), float(eps)), "gpvae_adam")
+
+
+def _dec_work(lib, Z, n, h0, h1, z):
+    nbytes = lib.gpvae_decoder_workspace_bytes(_dt(Z), Z.shape[0], n, h0, h1, z)
+    return torch.empty(nbytes, dtype=torch.uint8, device=Z.device)
+
+
+def decoder_fwd(dec_params, Z, n, h0, h1):
+    """F[c] = decoder(params, Z[c]); dec_params flat: V1 c1 V2 c2 V3 c3."""
+    _dev(dec_params, Z)
+    Z = Z.contiguous()
+    C_, z = Z.shape
+    F = torch.empty((C_, n), dtype=Z.dtype, device=Z.device)
+    lib = _lib.load()
+    check(lib.gpvae_decoder_fwd(_stream(), _dt(Z), C_, n, h0, h1, z, _p(dec_params), _p(Z), _p(F),
+                                _p(_dec_work(lib, Z, n, h0, h1, z))), "gpvae_decoder_fwd")
+    return F
+
+
+def decoder_vjp(dec_params, Z, dF, h0, h1):
+    _dev(dec_params, Z, dF)
+    Z, dF = Z.contiguous(), dF.contiguous()
+    C_, z = Z.shape
+    n = dF.shape[1]
+    dZ = torch.empty_like(Z)
+    lib = _lib.load()
+    check(lib.gpvae_decoder_vjp(_stream(), _dt(Z), C_, n, h0, h1, z, _p(dec_params), _p(Z), _p(dF),
+                                _p(dZ), _p(_dec_work(lib, Z, n, h0, h1, z))), "gpvae_decoder_vjp")
+    return dZ

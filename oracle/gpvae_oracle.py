@@ -154,3 +154,194 @@ def randn(count, seed=0, stream_id=0, dtype=np.float32):
         out[:, 2 * h] = rad * np.cos(np.pi * ang.astype(np.float64)).astype(dtype)
         out[:, 2 * h + 1] = rad * np.sin(np.pi * ang.astype(np.float64)).astype(dtype)
     return out.reshape(-1)[:count]
+
+
+# --------------------------------------------------------------------------------------------------
+# a9  GPInference.gp_prediction  (src/model/inference.py:427-460), literal
+# --------------------------------------------------------------------------------------------------
+
+
+def gp_prediction(x, y, obs_idx, var, ls, sigma, xi=None, jitter=1.0e-5, kernel=exp_kernel2):
+    """Returns (mean, mean + noise, diagK).  xi stands in for jax.random.normal(rng_key, (n_test,))."""
+    x, y = np.asarray(x), np.asarray(y)
+    obs_idx = np.asarray(obs_idx)
+    dt = x.dtype.type
+    x_test = np.delete(x, obs_idx, axis=0)  # inference.py:442
+    x_obs = x[obs_idx]  # inference.py:443
+    k_pp = kernel(x_test, x_test, var, ls, jitter)  # inference.py:447
+    k_px = kernel(x_test, x_obs, var, ls, jitter)  # inference.py:448
+    k_xx = kernel(x_obs, x_obs, var, ls, jitter)  # inference.py:449
+    k_xx_inv = np.linalg.inv(k_xx + np.eye(len(obs_idx), dtype=x.dtype) * dt(sigma))  # :450
+    K = k_pp - k_px @ (k_xx_inv @ k_px.T)  # inference.py:451
+    dK = np.clip(np.diag(K), 0.0, None)  # inference.py:452
+    mean = k_px @ (k_xx_inv @ y[obs_idx])  # inference.py:455
+    noise = np.sqrt(dK) * (xi if xi is not None else 0)
+    return mean.astype(x.dtype), (mean + noise).astype(x.dtype), np.diag(K).astype(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# a5/a6  stax encoder/decoder + Trace_ELBO loss  (src/model/vae.py:72-137, 213-218)
+# --------------------------------------------------------------------------------------------------
+
+PARAM_NAMES = ("W1", "b1", "W2", "b2", "Wmu", "bmu", "Wsd", "bsd", "V1", "c1", "V2", "c2", "V3", "c3")
+
+
+def param_shapes(n, h0, h1, z):
+    return {"W1": (n, h0), "b1": (h0,), "W2": (h0, h1), "b2": (h1,), "Wmu": (h1, z), "bmu": (z,),
+            "Wsd": (h1, z), "bsd": (z,), "V1": (z, h1), "c1": (h1,), "V2": (h1, h0), "c2": (h0,),
+            "V3": (h0, n), "c3": (n,)}
+
+
+def unflatten(flat, n, h0, h1, z):
+    out, o = {}, 0
+    for k in PARAM_NAMES:
+        shp = param_shapes(n, h0, h1, z)[k]
+        sz = int(np.prod(shp))
+        out[k] = flat[o:o + sz].reshape(shp)
+        o += sz
+    assert o == flat.size
+    return out
+
+
+def flatten(p):
+    return np.concatenate([np.asarray(p[k]).reshape(-1) for k in PARAM_NAMES])
+
+
+def init_params(rng, n, h0, h1, z, dtype=np.float32):
+    """stax.randn() W_init and the default bias init are both 1e-2 * N(0,1) (vae.py:76-95)."""
+    return {k: (1e-2 * rng.standard_normal(s)).astype(dtype) for k, s in param_shapes(n, h0, h1, z).items()}
+
+
+def encoder(p, y):
+    """stax.serial(Dense, Relu, Dense, Relu, FanOut(2), parallel(Dense, serial(Dense, Exp))) vae.py:75-85"""
+    h1_ = np.maximum(y @ p["W1"] + p["b1"], 0)
+    h2_ = np.maximum(h1_ @ p["W2"] + p["b2"], 0)
+    return h2_ @ p["Wmu"] + p["bmu"], np.exp(h2_ @ p["Wsd"] + p["bsd"])
+
+
+def decoder(p, zz):
+    """stax.serial(Dense(h1), Relu, Dense(h0), Relu, Dense(out_dim))  vae.py:90-96"""
+    d1 = np.maximum(zz @ p["V1"] + p["c1"], 0)
+    d2 = np.maximum(d1 @ p["V2"] + p["c2"], 0)
+    return d2 @ p["V3"] + p["c3"]
+
+
+def decoder_from_list(params_list, zz):
+    """decoder(decoder_params, z) with the stax list layout [(W,b),(),(W,b),(),(W,b)] (fixtures §4)."""
+    (V1, c1), _, (V2, c2), _, (V3, c3) = params_list
+    return decoder({"V1": V1, "c1": c1, "V2": V2, "c2": c2, "V3": V3, "c3": c3}, zz)
+
+
+_HALF_LOG_2PI = 0.9189385332046727
+
+
+def _normal_logpdf(v, loc, scale):
+    return -0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - _HALF_LOG_2PI
+
+
+def elbo_loss(p, y, eps_z, obs_sigma=0.1):
+    """-ELBO, one particle, summed over batch and dims (Trace_ELBO with vae_guide then vae_model
+    replayed on the guide's z; vae.py:98-137).  eps_z stands in for the guide's Normal draw."""
+    dt = y.dtype.type
+    z_loc, z_std = encoder(p, y)
+    zz = z_loc + z_std * eps_z  # z ~ Normal(z_loc, z_std)          vae.py:135
+    log_q = np.sum(_normal_logpdf(zz, z_loc, z_std))
+    log_pz = np.sum(_normal_logpdf(zz, dt(0), dt(1)))  # vae.py:112-114
+    f = decoder(p, zz)  # vae.py:115
+    log_py = np.sum(_normal_logpdf(y, f, dt(obs_sigma)))  # vae.py:117
+    return -(log_py + log_pz - log_q)
+
+
+def elbo_loss_and_grads(p, y, eps_z, obs_sigma=0.1):
+    """Loss and hand-derived reverse-mode gradients (what value_and_grad gives svi.update)."""
+    dt = y.dtype.type
+    A1 = y @ p["W1"] + p["b1"]; H1 = np.maximum(A1, 0)
+    A2 = H1 @ p["W2"] + p["b2"]; H2 = np.maximum(A2, 0)
+    MU = H2 @ p["Wmu"] + p["bmu"]; LS = H2 @ p["Wsd"] + p["bsd"]; SD = np.exp(LS)
+    Z = MU + SD * eps_z
+    G1 = Z @ p["V1"] + p["c1"]; D1 = np.maximum(G1, 0)
+    G2 = D1 @ p["V2"] + p["c2"]; D2 = np.maximum(G2, 0)
+    F = D2 @ p["V3"] + p["c3"]
+    s2 = dt(obs_sigma) ** 2
+    loss = (np.sum(0.5 * (y - F) ** 2 / s2) + y.size * (np.log(obs_sigma) + _HALF_LOG_2PI)
+            + np.sum(0.5 * Z * Z - 0.5 * eps_z * eps_z - LS))
+    dF = (F - y) / s2
+    g = {}
+    g["V3"] = D2.T @ dF; g["c3"] = dF.sum(0); dD2 = dF @ p["V3"].T
+    dG2 = dD2 * (G2 > 0); g["V2"] = D1.T @ dG2; g["c2"] = dG2.sum(0); dD1 = dG2 @ p["V2"].T
+    dG1 = dD1 * (G1 > 0); g["V1"] = Z.T @ dG1; g["c1"] = dG1.sum(0); dZ = dG1 @ p["V1"].T + Z
+    dMU = dZ; dLS = dZ * eps_z * SD - 1
+    g["Wmu"] = H2.T @ dMU; g["bmu"] = dMU.sum(0); g["Wsd"] = H2.T @ dLS; g["bsd"] = dLS.sum(0)
+    dH2 = dMU @ p["Wmu"].T + dLS @ p["Wsd"].T
+    dA2 = dH2 * (A2 > 0); g["W2"] = H1.T @ dA2; g["b2"] = dA2.sum(0); dH1 = dA2 @ p["W2"].T
+    dA1 = dH1 * (A1 > 0); g["W1"] = y.T @ dA1; g["b1"] = dA1.sum(0)
+    return loss, {k: v.astype(y.dtype) for k, v in g.items()}
+
+
+def decoder_vjp(p, zz, dF):
+    """dZ = (d decoder / d z)^T dF, per row."""
+    G1 = zz @ p["V1"] + p["c1"]; D1 = np.maximum(G1, 0)
+    G2 = D1 @ p["V2"] + p["c2"]
+    dD2 = dF @ p["V3"].T
+    dD1 = (dD2 * (G2 > 0)) @ p["V2"].T
+    return (dD1 * (G1 > 0)) @ p["V1"].T
+
+
+# --------------------------------------------------------------------------------------------------
+# a7  Adam as numpyro.optim.Adam -> jax.experimental.optimizers.adam  (vae.py:212)
+# --------------------------------------------------------------------------------------------------
+
+
+def adam_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """One update, step t counts from 1 (jax: i = t-1; mhat = m/(1-b1^(i+1)))."""
+    dt = p.dtype.type
+    m = (1 - dt(b1)) * g + dt(b1) * m
+    v = (1 - dt(b2)) * g * g + dt(b2) * v
+    mhat = m / dt(1 - b1 ** t)
+    vhat = v / dt(1 - b2 ** t)
+    p = p - dt(lr) * mhat / (np.sqrt(vhat) + dt(eps))
+    return p.astype(m.dtype), m, v
+
+
+# --------------------------------------------------------------------------------------------------
+# hyper-priors of GP.sample / epoch_train  (gp.py:171-176, vae.py:157-159), host-side draws
+# --------------------------------------------------------------------------------------------------
+
+
+def draw_hyper(rng):
+    """(ls, var, sigma): InverseGamma(1, 0.1), LogNormal(0, 0.1), HalfNormal(0.1)."""
+    ls = 0.1 / rng.gamma(1.0)  # InverseGamma(a, b) = b / Gamma(a, 1)
+    var = float(np.exp(0.1 * rng.standard_normal()))
+    sigma = abs(0.1 * rng.standard_normal())
+    return float(ls), var, float(sigma)
+
+
+def train_step(p, m, v, t, x, hyper, eps, eps2, eps_z, lr, jitter, obs_sigma=0.1):
+    """One body_fn of VAE.epoch_train (vae.py:150-167) with every random input explicit."""
+    ls, var, sigma = hyper
+    K = exp_kernel2(x, x, var, ls, jitter)  # gp.py:188
+    L = cholesky_lower(K)
+    _, Y = gp_draw(L, eps, sigma, eps2)  # gp.py:190-194 under Predictive
+    loss, g = elbo_loss_and_grads(p, Y, eps_z, obs_sigma)
+    out_p, out_m, out_v = {}, {}, {}
+    for k in PARAM_NAMES:
+        out_p[k], out_m[k], out_v[k] = adam_step(p[k], g[k], m[k], v[k], t, lr)
+    return loss, out_p, out_m, out_v
+
+
+# --------------------------------------------------------------------------------------------------
+# a11  VAEInference.regression potential (src/model/inference.py:243-254), unconstrained space
+# --------------------------------------------------------------------------------------------------
+
+
+def vae_potential(p, zz, log_sigma, y, obs_idx, s0=0.1):
+    """-log joint of (noise ~ HalfNormal(s0), z ~ N(0,I), y[obs] ~ Normal(decoder(z)[obs], noise))
+    with noise = exp(log_sigma) and the log-Jacobian of that transform (NumPyro's potential)."""
+    sigma = np.exp(log_sigma)
+    f = decoder(p, zz)
+    r = f[..., obs_idx] - y[obs_idx]
+    log_lik = np.sum(_normal_logpdf(y[obs_idx], f[..., obs_idx], sigma[..., None]), axis=-1)
+    log_pz = np.sum(_normal_logpdf(zz, 0.0, 1.0), axis=-1)
+    log_ps = np.log(2.0) - _HALF_LOG_2PI - np.log(s0) - 0.5 * (sigma / s0) ** 2 + log_sigma
+    del r
+    return -(log_lik + log_pz + log_ps)

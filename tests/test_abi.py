@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/gpvae.h
+declares, and validates arguments without touching a GPU (no compute call is made here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gp_vae_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "gpvae.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpvae_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) == 17
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.gpvae_abi_version() == 1
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "gpvae.h")).read()
+    assert "torch" not in src.lower().replace("no torch", "") and "at::" not in src and 'extern "C"' in src
+
+
+def test_argument_validation_without_a_gpu():
+    lib = _lib.load()
+    null = C.c_void_p(0)
+    # bad dtype -> -(index of dtype argument) = -2, and a readable reason
+    assert lib.gpvae_gram_se(null, 7, 1, 4, 4, null, null, 1, null, null, 0.0, null, 4, 16) == -2
+    assert b"dtype" in lib.gpvae_last_error()
+    assert lib.gpvae_gram_se(null, 0, 3, 4, 4, null, null, 1, null, null, 0.0, null, 4, 16) == -3
+    assert lib.gpvae_gram_se(null, 0, 1, 4, 4, null, null, 1, null, null, 0.0, null, 4, 16) == -6  # x NULL
+    assert lib.gpvae_potrf(null, 0, -1, 1, null, 0, 0, 0, null, 0, 0, null, 0, null) == -3
+    assert lib.gpvae_potrf(null, 0, 8, 1, null, 8, 64, 0, null, 0, 0, null, 0, null) == -5  # A NULL
+    assert lib.gpvae_draw(null, 0, 8, 4, null, 8, null, 8, null, 0, null, null, 0, null, 0) == -5
+    assert lib.gpvae_adam(null, 0, 10, null, null, null, null, 0, 1e-3, 0.9, 0.999, 1e-8) == -8  # t >= 1
+    assert lib.gpvae_vae_elbo(null, 0, 4, 8, 0, 2, 2, null, null, 8, null, 0.1, null, null, null) == -5
+    assert lib.gpvae_krig_predict(null, 0, 3, 4, 4, null, null, null, null, null, null, 0.0, null,
+                                  null, null, null, null, null) == -3
+    # empty problems are accepted and do nothing
+    assert lib.gpvae_gram_se(null, 0, 1, 0, 4, null, null, 1, null, null, 0.0, null, 4, 0) == 0
+    assert lib.gpvae_potrf(null, 0, 0, 1, null, 0, 0, 0, null, 0, 0, null, 0, null) == 0
+    assert lib.gpvae_draw(null, 0, 0, 4, null, 0, null, 0, null, 0, null, null, 0, null, 0) == 0
+
+
+def test_size_queries():
+    lib = _lib.load()
+    n, h0, h1, z = 300, 35, 30, 10
+    want = n * h0 + h0 + h0 * h1 + h1 + 2 * (h1 * z + z) + z * h1 + h1 + h1 * h0 + h0 + h0 * n + n
+    assert lib.gpvae_vae_param_count(n, h0, h1, z) == want
+    assert lib.gpvae_vae_workspace_bytes(0, 100, n, h0, h1, z) >= 100 * n * 4
+    assert lib.gpvae_vae_workspace_bytes(1, 100, n, h0, h1, z) >= 100 * n * 8
+    assert lib.gpvae_krig_workspace_bytes(1, 100, 50) >= (100 * 100 + 51 * 100) * 8
+    assert lib.gpvae_potrf_workspace_bytes(0, 4096, 0, 32) == 0
+
+
+def test_cpu_tensors_are_refused_loudly():
+    import torch
+    from gp_vae_amd import GpvaeError, ops
+    x = torch.zeros(4)
+    with pytest.raises(GpvaeError):
+        ops.gram_se(x, x, 1.0, 1.0)
+    with pytest.raises(GpvaeError):
+        ops.potrf_(torch.eye(4))

@@ -1,0 +1,335 @@
+"""GPU parity tests: every hot-path entry point, called through the C ABI (gp_vae_amd.ops ->
+libgpvae_hip.so), against the CPU oracle on identical inputs.
+
+Tolerances (BASELINE.json north_star): 1e-5 relative in float64 (we assert 1e-9 or better where
+the arithmetic allows), 1e-3 relative in float32 with the scripts' default jitters.  For float32
+Cholesky FACTORS the attainable forward error is cond(K)*eps, whichever algorithm is used
+(SURVEY.md §6), so the assertion is  err <= max(1e-3, 3 * err of LAPACK's own float32 factor)
+plus a backward-error bound ||L L^T - K|| / ||K|| <= 2e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [(np.float64, torch.float64, 1e-9), (np.float32, torch.float32, 1e-3)]
+
+
+def rel(a, b):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a, tdt):
+    return torch.tensor(np.asarray(a), dtype=tdt, device=DEV)
+
+
+def grid2(g):
+    gg = np.arange(0, 1, 1 / g)
+    u, v = np.meshgrid(gg, gg)
+    return np.stack([u.ravel(), v.ravel()], 1)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gp_vae_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+# ---- a1 ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_gram_golden_and_edges(ops, golden, ndt, tdt, tol):
+    g = golden
+    gt = 1e-12 if ndt == np.float64 else 1e-6
+    cases = [("gram_x16", "gram_x16", 1.3, 0.15, 1e-4, "gram_k16"), ("gram_x44", "gram_x44", 0.9, 0.4, 1e-3, "gram_k44"),
+             ("gram_xa", "gram_xb", 1.1, 0.3, 1e-2, "gram_rect"), ("gram_xc", "gram_xd", 1.0, 0.5, 1e-2, "gram_sqdiff")]
+    for xa, xb, var, ls, jit, want in cases:
+        k = ops.gram_se(dev(g[xa], tdt), dev(g[xb], tdt), var, ls, jit)
+        assert rel(k, g[want]) < gt, want
+    # ragged sizes (not multiples of the 4-wide store / 256-wide block), 1-D and 2-D
+    rng = np.random.default_rng(0)
+    for nx, nz, d in ((1, 1, 1), (3, 257, 1), (130, 67, 2), (33, 33, 2)):
+        x, z = rng.random((nx, d)).astype(ndt), rng.random((nz, d)).astype(ndt)
+        k = ops.gram_se(dev(x, tdt), dev(z, tdt), 0.7, 0.25, 1e-3)
+        assert k.shape == (nx, nz) and rel(k, orc.exp_kernel2(x.astype(np.float64), z.astype(np.float64), 0.7, 0.25, 1e-3)) < gt
+    # batched hyper-parameters
+    x = np.arange(0, 1, 1 / 50).astype(ndt)
+    var, ls = np.array([1.0, 0.5, 2.0]), np.array([0.05, 0.3, 1.0])
+    kb = ops.gram_se(dev(x, tdt), dev(x, tdt), dev(var, tdt), dev(ls, tdt), 1e-4)
+    for b in range(3):
+        assert rel(kb[b], orc.exp_kernel2(x.astype(np.float64), x.astype(np.float64), var[b], ls[b], 1e-4)) < gt
+    # empty input
+    assert ops.gram_se(dev(np.zeros((0,)), tdt), dev(x, tdt), 1.0, 1.0).shape == (0, 50)
+
+
+def test_gram_full_size_properties(ops):
+    x = dev(grid2(64), torch.float32)  # C3: 64x64 grid
+    k = ops.gram_se(x, x, 1.0, 0.3, 1e-3)
+    assert k.shape == (4096, 4096)
+    assert torch.equal(k, k.T) and torch.allclose(torch.diagonal(k), torch.full((4096,), 1.001, device=DEV))
+    idx = np.random.default_rng(0).integers(0, 4096, 64)
+    sub = orc.exp_kernel2(grid2(64)[idx], grid2(64)[idx], 1.0, 0.3, 0.0)
+    got = k[idx][:, idx].cpu().numpy() - 1e-3 * (idx[:, None] == idx[None, :])
+    assert np.abs(got - sub).max() < 1e-6
+
+
+# ---- a2 ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_agg_kernel(ops, golden, ndt, tdt, tol):
+    gt = 1e-12 if ndt == np.float64 else 1e-6
+    assert rel(ops.gram_agg(dev(golden["agg_pts1"], tdt), 1.2, 0.2, 1e-3), golden["agg_k1"]) < gt
+    assert rel(ops.gram_agg(dev(golden["agg_pts2"], tdt), 0.8, 0.3, 1e-3), golden["agg_k2"]) < gt
+    rng = np.random.default_rng(3)
+    pts = orc.agg_points(rng.random((37, 3, 1)), np.arange(0, 1, 1 / 37), d=1)  # ragged vs 16x16 tiles
+    assert rel(ops.gram_agg(dev(pts, tdt), 1.0, 0.1, 0.0), orc.agg_kernel_from_points(pts, 1.0, 0.1, 0.0)) < gt
+
+
+def test_agg_kernel_grid_surface(ops):
+    from gp_vae_amd import gp
+    grid = np.arange(0, 1, 1 / 6)
+    k = gp.agg_kernel_grid(3, 2, 4, gp.exp_kernel2, 1.0, 0.3, grid)
+    assert k.shape == (36, 36) and torch.allclose(k, k.T, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        gp.agg_kernel_grid(3, 1, 4, lambda *a: None, 1.0, 0.3, grid)
+
+
+# ---- a3 ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("n", [8, 64, 300, 625])
+def test_potrf_golden(ops, golden, ndt, tdt, tol, n):
+    var, ls, jit = golden["chol_n%d_hyp" % n]
+    x = golden["chol_n%d_x" % n]
+    K64 = orc.exp_kernel2(x, x, var, ls, jit)
+    L64 = orc.cholesky_lower(K64)
+    if n <= 64:
+        assert rel(L64, golden["chol_n%d_L" % n]) < 1e-12
+    A = ops.gram_se(dev(x, tdt), dev(x, tdt), var, ls, jit).clone()
+    Kd = A.clone()
+    info = ops.potrf_(A)
+    assert info.item() == 0
+    L = A.cpu().numpy().astype(np.float64)
+    assert np.all(np.triu(L, 1) == 0)  # clean lower factor, as jnp.linalg.cholesky returns
+    Kh = Kd.cpu().numpy().astype(np.float64)
+    assert rel(L @ L.T, Kh) < (1e-14 if ndt == np.float64 else 2e-6)
+    err = rel(L, L64)
+    if ndt == np.float64:
+        assert err < tol
+    else:
+        lap = rel(np.linalg.cholesky(Kh.astype(np.float32)), L64)
+        assert err < max(1e-3, 3 * lap), (err, lap)
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_potrf_non_pd_batched_and_trailing_rows(ops, ndt, tdt, tol):
+    rng = np.random.default_rng(1)
+    # batch of 3, the middle one indefinite from column 70 on
+    n = 150
+    x = np.sort(rng.random(n))
+    Ks = np.stack([orc.exp_kernel2(x, x, 1.0, ls, 1e-3) for ls in (0.05, 0.1, 0.2)])
+    Ks[1, 69, 69] = -5.0
+    A = dev(Ks, tdt)
+    info = ops.potrf_(A)
+    assert info.cpu().tolist() == [0, 70, 0]
+    assert torch.isnan(A[1]).all()  # jnp.linalg.cholesky semantics: failed factor is all NaN
+    for b in (0, 2):
+        assert rel(A[b], orc.cholesky_lower(Ks[b])) < (1e-9 if ndt == np.float64 else 5e-3)
+    A2 = dev(Ks, tdt)
+    info2 = ops.potrf_(A2, zero_upper=False, nan_on_fail=False)  # LAPACK-style: info only
+    assert info2.cpu().tolist() == [0, 70, 0] and not torch.isnan(A2[0]).any()
+    # trailing rows ride along: X <- X L^-T, several workgroups' worth, ragged n and lda != n
+    for n, m in ((10, 291), (100, 526), (257, 130)):
+        x = np.sort(rng.random(n))
+        K = orc.exp_kernel2(x, x, 1.0, 0.2, 1e-5) + 0.05 * np.eye(n)
+        X = rng.standard_normal((m, n))
+        ld = n + 5
+        Abuf = torch.zeros((n, ld), dtype=tdt, device=DEV)
+        Xbuf = torch.zeros((m, ld), dtype=tdt, device=DEV)
+        Abuf[:, :n] = dev(K, tdt)
+        Xbuf[:, :n] = dev(X, tdt)
+        assert ops.potrf_(Abuf[:, :n], Xbuf[:, :n]).item() == 0
+        L = orc.cholesky_lower(K)
+        t = 1e-9 if ndt == np.float64 else 2e-3
+        assert rel(Abuf[:, :n], L) < t and rel(Xbuf[:, :n], orc.right_solve_lt(L, X)) < t
+        assert torch.all(Abuf[:, n:] == 0) and torch.all(Xbuf[:, n:] == 0)  # padding untouched
+
+
+def test_potrf_full_size_backward_error(ops):
+    x = dev(grid2(64), torch.float32)  # C3 size, script jitter (2d_examples.py:503)
+    ls = torch.tensor([0.05, 0.3, 1.0], device=DEV)
+    K = ops.gram_se(x, x, torch.ones(3, device=DEV), ls, 1e-3)
+    A = K.clone()
+    info = ops.potrf_(A)
+    assert info.cpu().tolist() == [0, 0, 0]
+    for b in range(3):
+        L = A[b].double()
+        assert (torch.linalg.norm(L @ L.T - K[b].double()) / torch.linalg.norm(K[b].double())).item() < 2e-6
+    x1 = dev(np.arange(0, 1, 1 / 1024), torch.float64)  # C2 size in float64 against LAPACK
+    K1 = ops.gram_se(x1, x1, 1.0, 0.05, 1e-4)
+    A1 = K1.clone()
+    ops.potrf_(A1)
+    assert rel(A1, np.linalg.cholesky(K1.cpu().numpy())) < 1e-9
+
+
+# ---- a3/a4 draws -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_draw(ops, golden, ndt, tdt, tol):
+    gt = 1e-12 if ndt == np.float64 else 1e-5
+    L = golden["chol_n64_L"]
+    Ld = dev(L + np.triu(np.full((64, 64), 7.0), 1), tdt)  # garbage above the diagonal must be ignored
+    F, Y = ops.draw(Ld, dev(golden["draw_E"], tdt), dev(golden["draw_E2"], tdt), 0.07, want_f=True)
+    assert rel(F, golden["draw_F"]) < gt and rel(Y, golden["draw_Y"]) < gt
+    rng = np.random.default_rng(2)
+    for n, nb in ((1, 1), (130, 5), (300, 257), (625, 100)):
+        Lr = np.tril(rng.standard_normal((n, n)))
+        E, E2 = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
+        Fo, Yo = orc.gp_draw(Lr, E, 0.3, E2)
+        Yd = ops.draw(dev(Lr, tdt), dev(E, tdt), dev(E2, tdt), 0.3)
+        assert rel(Yd, Yo) < gt
+        assert rel(ops.draw(dev(Lr, tdt), dev(E, tdt)), Fo) < gt  # no noise term
+
+
+def test_draw_full_size_covariance(ops):
+    n, B = 4096, 4096
+    x = dev(grid2(64), torch.float32)
+    K = ops.gram_se(x, x, 1.0, 0.2, 1e-3)
+    A = K.clone()
+    ops.potrf_(A, zero_upper=False)
+    E = ops.randn((B, n), seed=3, stream_id=1)
+    Y = ops.draw(A, E)
+    # linearity: draw(E1 + E2) == draw(E1) + draw(E2)
+    E2 = ops.randn((B, n), seed=3, stream_id=2)
+    assert rel(ops.draw(A, E + E2), (Y + ops.draw(A, E2)).cpu().numpy()) < 1e-5
+    idx = torch.tensor(np.random.default_rng(0).integers(0, n, 32), device=DEV)
+    S = (Y[:, idx].double().T @ Y[:, idx].double() / B).cpu().numpy()
+    assert np.abs(S - K[idx][:, idx].cpu().numpy()).max() < 0.12  # ~ 5 sigma of a 4096-sample covariance
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_randn(ops, golden, ndt, tdt, tol):
+    want = golden["randn_f64" if ndt == np.float64 else "randn_f32"]
+    got = ops.randn((37,), tdt, DEV, seed=123456789012345, stream_id=9).cpu().numpy()
+    assert np.abs(got - want).max() < (1e-13 if ndt == np.float64 else 2e-6)
+    z = ops.randn((1 << 20,), tdt, DEV, seed=1, stream_id=0)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert not torch.equal(z[:1000], ops.randn((1000,), tdt, DEV, seed=1, stream_id=1))
+
+
+# ---- a9 kriging ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_kriging(ops, golden, ndt, tdt, tol):
+    g = golden
+    x, y, obs, xi = g["krig_x"], g["krig_y"], g["krig_obs"], g["krig_xi"]
+    var, ls, sig = g["krig_hyp"]
+    mask = np.ones(300, bool)
+    mask[obs] = False
+    m, s, v, info = ops.krig_predict(dev(x[obs], tdt), dev(x[mask], tdt), dev(y[obs], tdt), var, ls, sig, 1e-5, dev(xi, tdt))
+    t = 1e-8 if ndt == np.float64 else 1e-3
+    assert info.item() == 0
+    assert rel(m, g["krig_mean"]) < t and rel(s, g["krig_sample"]) < t and rel(v, g["krig_var"]) < t
+    # the n_test == n_obs quirk (jitter on k_px)
+    x2, y2, o2 = g["krigsq_x"], g["krigsq_y"], g["krigsq_obs"]
+    mk = np.ones(20, bool)
+    mk[o2] = False
+    m2, _, v2, _ = ops.krig_predict(dev(x2[o2], tdt), dev(x2[mk], tdt), dev(y2[o2], tdt), 1.0, 0.2, 0.05)
+    assert rel(m2, g["krigsq_mean"]) < t and rel(v2, g["krigsq_var"]) < (1e-7 if ndt == np.float64 else 5e-2)
+    # 2-D, several panels, against the literal inverse-based oracle
+    rng = np.random.default_rng(4)
+    xg = grid2(30)
+    o = np.sort(rng.permutation(900)[:400])
+    yy = np.sin(5 * xg[:, 0]) * np.cos(3 * xg[:, 1]) + 0.05 * rng.standard_normal(900)
+    mo, so, vo = orc.gp_prediction(xg, yy, o, 1.1, 0.25, 0.05, None)
+    mk = np.ones(900, bool)
+    mk[o] = False
+    md, _, vd, _ = ops.krig_predict(dev(xg[o], tdt), dev(xg[mk], tdt), dev(yy[o], tdt), 1.1, 0.25, 0.05)
+    assert rel(md, mo) < (1e-7 if ndt == np.float64 else 2e-3)
+    if ndt == np.float64:
+        assert np.abs(vd.cpu().numpy() - vo).max() < 1e-8
+
+
+def test_gpinference_surface(ops, golden):
+    from gp_vae_amd.gp import exp_kernel2
+    from gp_vae_amd.inference import GPInference
+    g = golden
+    inf = GPInference(exp_kernel2, 1, g["krig_x"], g["krig_y"], g["krig_obs"], {}, dtype=torch.float64)
+    var, ls, sig = g["krig_hyp"]
+    mean, pred = inf.gp_prediction(7, inf.x, inf.y, var, ls, sig)
+    assert rel(mean, g["krig_mean"]) < 1e-8 and mean.shape == pred.shape == (290,)
+    post = {"kernel_var": [1.0, 1.1], "kernel_length": [0.07, 0.1], "kernel_sigma": [0.03, 0.05]}
+    means, preds = inf.gp_fit_from_samples(1, post)
+    assert means.shape == (2, 290)
+    assert rel(means[1], orc.gp_prediction(g["krig_x"], g["krig_y"], g["krig_obs"], 1.1, 0.1, 0.05)[0]) < 1e-8
+
+
+# ---- a5/a6/a7/a11 --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_vae_elbo_adam_decoder_golden(ops, golden, ndt, tdt, tol):
+    g = golden
+    n, h0, h1, z, B = (int(v) for v in g["elbo_dims"])
+    t = 1e-11 if ndt == np.float64 else 2e-5
+    flat = dev(g["elbo_params"], tdt)
+    grads = torch.empty_like(flat)
+    loss = ops.vae_elbo(flat, dev(g["elbo_Y"], tdt), dev(g["elbo_eps"], tdt), (h0, h1, z), 0.1, grads=grads)
+    assert abs(loss.item() - g["elbo_loss"]) < t * abs(g["elbo_loss"])
+    go, gd = orc.unflatten(g["elbo_grads"], n, h0, h1, z), orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+    for k in orc.PARAM_NAMES:
+        assert rel(gd[k], go[k]) < t, k
+    loss2 = ops.vae_elbo(flat, dev(g["elbo_Y"], tdt), dev(g["elbo_eps"], tdt), (h0, h1, z), 0.1)  # svi.evaluate
+    assert abs(loss2.item() - g["elbo_loss"]) < t * abs(g["elbo_loss"])
+    p, m, v = flat.clone(), dev(g["adam_m0"], tdt), dev(g["adam_v0"], tdt)
+    ops.adam_(p, dev(g["elbo_grads"], tdt), m, v, 4, 1e-3)
+    ta = 1e-13 if ndt == np.float64 else 5e-5  # (1 - 0.999f) carries a 1.3e-5 rounding
+    assert rel(p, g["adam_p1"]) < ta and rel(m, g["adam_m1"]) < ta and rel(v, g["adam_v1"]) < ta
+    pp = orc.unflatten(g["elbo_params"], n, h0, h1, z)
+    dec = dev(np.concatenate([pp[k].reshape(-1) for k in ("V1", "c1", "V2", "c2", "V3", "c3")]), tdt)
+    assert rel(ops.decoder_fwd(dec, dev(g["dec_Z"], tdt), n, h0, h1), g["dec_F"]) < t
+    assert rel(ops.decoder_vjp(dec, dev(g["dec_Z"], tdt), dev(g["dec_dF"], tdt), h0, h1), g["dec_dZ"]) < t
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("dims", [(100, 300, 35, 30, 10), (37, 625, 50, 30, 15), (300, 1024, 64, 32, 16), (5, 19, 3, 2, 1)])
+def test_vae_elbo_reference_dims(ops, ndt, tdt, tol, dims):
+    B, n, h0, h1, z = dims  # reference 1-D / 2-D layer sizes (toy_examples.py:615-630, 2d_examples.py)
+    rng = np.random.default_rng(5)
+    p = {k: (10 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+    lo, go = orc.elbo_loss_and_grads(p, Y, ez, 0.1)
+    flat = dev(orc.flatten(p), tdt)
+    grads = torch.empty_like(flat)
+    loss = ops.vae_elbo(flat, dev(Y, tdt), dev(ez, tdt), (h0, h1, z), 0.1, grads=grads)
+    t = 1e-10 if ndt == np.float64 else 1e-4
+    assert abs(loss.item() - lo) < t * abs(lo)
+    gd = orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+    for k in orc.PARAM_NAMES:
+        assert rel(gd[k], go[k]) < t, k
+
+
+def test_vaeinference_potential_gradient(ops):
+    from gp_vae_amd.inference import VAEInference
+    rng = np.random.default_rng(6)
+    n, h0, h1, z = 300, 35, 30, 10  # shapes of the reference's pickled decoders (synthetic weights:
+    # the fixtures are pickles, which this build does not unpickle)
+    p = {k: 15 * v for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    lst = [(p["V1"], p["c1"]), (), (p["V2"], p["c2"]), (), (p["V3"], p["c3"])]
+    obs = np.array([20, 23, 100, 110, 117, 130, 133, 140, 170, 190])  # toy_examples.py:199
+    y = np.sin(np.arange(300) / 30.0)
+    inf = VAEInference(None, lst, z, 1, np.arange(0, 1, 1 / 300), y, obs, {}, dtype=torch.float64)
+    Z, u = rng.standard_normal((64, z)), np.log(0.1) + 0.3 * rng.standard_normal(64)
+    U, dz, du = inf.potential_and_grad(Z, u)
+    assert rel(U, orc.vae_potential(p, Z, u, y, obs)) < 1e-10
+    h = 1e-6
+    for i in range(z):
+        zp, zm = Z.copy(), Z.copy()
+        zp[:, i] += h
+        zm[:, i] -= h
+        fd = (orc.vae_potential(p, zp, u, y, obs) - orc.vae_potential(p, zm, u, y, obs)) / (2 * h)
+        assert np.allclose(dz[:, i].cpu().numpy(), fd, rtol=1e-5, atol=1e-5)
+    fd = (orc.vae_potential(p, Z, u + h, y, obs) - orc.vae_potential(p, Z, u - h, y, obs)) / (2 * h)
+    assert np.allclose(du.cpu().numpy(), fd, rtol=1e-5, atol=1e-5)
+    assert rel(inf.predict(Z), orc.decoder(p, Z)) < 1e-12

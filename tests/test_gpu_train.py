@@ -1,0 +1,77 @@
+"""GPU tests of the training loop (a8): the stream-overlapped StepEngine reproduces the oracle's
+train_step on identical inputs, and the reference-surface VAE.fit trains (C1 plumbing config)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
+def test_step_engine_matches_oracle_train_steps(tdt, ndt, tol):
+    from gp_vae_amd import ops, parallel
+    from gp_vae_amd.gp import draw_hyper
+    from gp_vae_amd.vae import StepEngine, SVIState
+    n, B, dims, lr, jit = 300, 100, (35, 30, 10), 1e-3, 1e-4  # C1: toy_examples.py:612-630
+    x = np.arange(0, 1, 1 / n)
+    eng = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=tdt, seed=1)
+    rng = np.random.default_rng(0)
+    p = {k: 5 * v for k, v in orc.init_params(rng, n, *dims, np.float64).items()}
+    state = SVIState(torch.tensor(orc.flatten(p), dtype=tdt, device=DEV))
+    keys = [(9, i) for i in range(4)]
+    loss_sum = eng.run(keys, state, train=True).item()
+    # replay on the oracle with the very same random inputs (device Philox streams read back)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(a) for k, a in p.items()}
+    want = 0.0
+    for t, key in enumerate(keys, 1):
+        ls, var, sig = draw_hyper(parallel.step_rng(1, 0, key))
+        E, E2, ez = (ops.randn(s, tdt, DEV, seed=1, stream_id=parallel.philox_stream_id(0, key, i)).cpu().numpy().astype(np.float64)
+                     for i, s in ((1, (B, n)), (2, (B, n)), (3, (B, dims[2]))))
+        loss, p, m, v = orc.train_step(p, m, v, t, x, (ls, var, sig), E, E2, ez, lr, jit)
+        want += loss
+    assert abs(loss_sum - want) < tol * abs(want)
+    assert rel(state.params.cpu().numpy(), orc.flatten(p)) < tol
+    # evaluation leaves the state alone (svi.evaluate, vae.py:194)
+    before = state.params.clone()
+    eng.run([(3, 0), (3, 1)], state, train=False)
+    assert torch.equal(before, state.params) and state.t == 4
+    # overlap on/off is the same arithmetic
+    eng2 = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=tdt, seed=1, overlap=False)
+    st2 = SVIState(torch.tensor(orc.flatten({k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}), dtype=tdt, device=DEV))
+    l2 = eng2.run(keys, st2, train=True).item()
+    assert abs(l2 - loss_sum) <= 1e-5 * abs(loss_sum)
+
+
+def test_vae_fit_reference_surface_trains():
+    from gp_vae_amd.gp import GP, Predictive, exp_kernel2
+    from gp_vae_amd.vae import VAE
+    n = 300
+    x = np.arange(0, 1, 1 / n)
+    gp = GP(kernel=exp_kernel2, jitter=1e-4, d=1)  # toy_examples.py:142,612
+    vae = VAE(gp, [35, 30], 10, n, 100, 1e-3, 3, 150, 20, x, seed=1)  # toy_examples.py:148-160 (short)
+    params = vae.fit(plot_loss=False)
+    assert len(vae.test_loss_list) == 3 and np.all(np.isfinite(vae.test_loss_list))
+    # the ELBO improves: same held-out batches (same key => same GP draws) before and after training
+    l_before = vae.eval_test(42, vae.svi_init())
+    l_after = vae.eval_test(42, vae.state)
+    assert l_after < 0.7 * l_before, (l_before, l_after)
+    assert [tuple(a.shape) for a in (params[0][0], params[2][0], params[4][0])] == [(10, 30), (30, 35), (35, 300)]
+    _, apply = vae.vae_decoder()
+    z = torch.zeros(10)
+    assert apply(params, z).shape == (300,)
+    # Predictive(gp.sample) call shapes (vae.py:223-226, toy_examples.py:88)
+    pred = Predictive(gp.sample, num_samples=12)
+    out = pred(5, x=x)  # hyper-parameters drawn per sample: batched Cholesky path
+    assert out["y"].shape == (12, n) and out["length"].shape == (12,) and torch.isfinite(out["y"]).all()
+    out2 = pred(5, x=x, ls=0.05, var=1.0, sigma=0.01)
+    assert out2["y"].shape == (12, n) and "length" not in out2
+    assert (out2["y"] - out2["f"]).std().item() < 0.02

@@ -1,0 +1,99 @@
+"""CPU tests of the host logic above the C ABI (parameter layouts, seeds, sharding) and of the
+data-parallel step on world_size 2 (gloo): gradients of two ranks' own batches, all-reduced with
+the product's one collective, equal the gradient of the concatenated batch, and both ranks end
+with identical parameters.  The compute stand-in in these tests is the oracle (tests only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gp_vae_amd import gp as gpmod
+from gp_vae_amd import parallel, vae as vaemod
+from oracle import gpvae_oracle as orc
+
+
+def test_decoder_list_roundtrip_matches_reference_layout():
+    n, h0, h1, z = 300, 35, 30, 10  # the shapes of the reference's pickled decoders
+    P = n * h0 + h0 + h0 * h1 + h1 + 2 * (h1 * z + z) + z * h1 + h1 + h1 * h0 + h0 + h0 * n + n
+    flat = torch.arange(P, dtype=torch.float64)
+    lst = vaemod.decoder_list_from_flat(flat, n, h0, h1, z)
+    assert [tuple(a.shape) for a in (lst[0][0], lst[2][0], lst[4][0])] == [(10, 30), (30, 35), (35, 300)]
+    assert lst[1] == () and lst[3] == () and len(lst) == 5
+    p = orc.unflatten(flat.numpy(), n, h0, h1, z)
+    assert np.array_equal(lst[0][0].numpy(), p["V1"]) and np.array_equal(lst[4][1].numpy(), p["c3"])
+    assert np.array_equal(lst[2][0].numpy(), p["V2"]) and np.array_equal(lst[2][1].numpy(), p["c2"])
+
+
+def test_seed_and_stream_ids():
+    assert gpmod._seed_of(5) == 5 and gpmod._seed_of(None) == 0
+    assert gpmod._seed_of(np.array([1, 2], dtype=np.uint32)) != gpmod._seed_of(np.array([2, 1], dtype=np.uint32))
+    ids = {parallel.philox_stream_id(r, (e, s), p) for r in range(8) for e in (1, 2) for s in range(50) for p in (1, 2, 3)}
+    assert len(ids) == 8 * 2 * 50 * 3
+    a = parallel.step_rng(3, 0, (7, 1)).random()
+    assert a == parallel.step_rng(3, 0, (7, 1)).random() and a != parallel.step_rng(3, 1, (7, 1)).random()
+
+
+def test_hyper_sampler_matches_oracle_priors():
+    rng = np.random.default_rng(0)
+    ls, var, sig = gpmod.draw_hyper(rng, 40000)
+    assert abs(np.median(ls) - 0.1 / np.log(2)) < 0.01
+    assert abs(np.std(np.log(var)) - 0.1) < 0.005 and abs(np.mean(sig) - 0.1 * np.sqrt(2 / np.pi)) < 0.002
+
+
+def test_shard_covers_everything_once():
+    got = sorted(i for r in range(8) for i in parallel.shard(1024, r, 8))
+    assert got == list(range(1024)) and len(parallel.shard(1024, 3, 8)) == 128
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, h0, h1, z, B = 24, 5, 4, 3, 6
+        x = np.arange(0, 1, 1 / n)
+        rng0 = np.random.default_rng(11)
+        p = orc.init_params(rng0, n, h0, h1, z, np.float64)
+        m = {k: np.zeros_like(v) for k, v in p.items()}
+        v = {k: np.zeros_like(a) for k, a in p.items()}
+        batches = []
+        for t in range(1, 4):
+            key = (5, t)
+            assert parallel.dist_info() == (rank, world)
+            hyper = gpmod.draw_hyper(parallel.step_rng(0, rank, key))  # ranks draw different GPs
+            r = np.random.default_rng([rank, t])
+            E, E2, ez = r.standard_normal((B, n)), r.standard_normal((B, n)), r.standard_normal((B, z))
+            K = orc.exp_kernel2(x, x, hyper[1], hyper[0], 1e-4)
+            _, Y = orc.gp_draw(orc.cholesky_lower(K), E, hyper[2], E2)
+            loss, g = orc.elbo_loss_and_grads(p, Y, ez)
+            flat = torch.from_numpy(orc.flatten(g).copy())
+            parallel.allreduce_sum_(flat)  # the product's one collective
+            g = orc.unflatten(flat.numpy(), n, h0, h1, z)
+            for k in orc.PARAM_NAMES:
+                p[k], m[k], v[k] = orc.adam_step(p[k], g[k], m[k], v[k], t, 1e-3)
+            batches.append((Y, ez, flat.numpy().copy()))
+        np.savez(os.path.join(tmp, "rank%d.npz" % rank), params=orc.flatten(p),
+                 **{"Y%d" % i: b[0] for i, b in enumerate(batches)},
+                 **{"e%d" % i: b[1] for i, b in enumerate(batches)},
+                 **{"g%d" % i: b[2] for i, b in enumerate(batches)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_world2_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["params"], r1["params"])  # replicas stay identical
+    assert np.array_equal(r0["g0"], r1["g0"])
+    # summed gradient == gradient of the concatenated batch (the loss is a SUM, vae.py:165-166)
+    n, h0, h1, z = 24, 5, 4, 3
+    p = orc.init_params(np.random.default_rng(11), n, h0, h1, z, np.float64)
+    Y = np.concatenate([r0["Y0"], r1["Y0"]])
+    ez = np.concatenate([r0["e0"], r1["e0"]])
+    _, g = orc.elbo_loss_and_grads(p, Y, ez)
+    assert np.allclose(orc.flatten(g), r0["g0"], rtol=1e-10, atol=1e-10)
+    assert not np.array_equal(r0["Y0"], r1["Y0"])  # the ranks really drew different batches
