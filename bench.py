@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — GP-prior VAE training draws/s at the 64x64 grid (BASELINE.json metric, config C3).
+
+One "step" = one full training step on one synthetic batch, nothing skipped:
+  draw (ls, var, sigma) -> Gram 4096x4096 -> Cholesky -> B = 4096 MVN draws y = L eps + sigma eps'
+  -> VAE ELBO forward + backward (2d reference layers 50/30/15) -> [all-reduce] -> Adam.
+float32 throughout (the reference's dtype).  Data are synthetic by construction (GP draws).
+N > 1: one process per GPU (torch.distributed "nccl" = RCCL), every rank draws its own GP and its
+own B functions (weak scaling), one gradient all-reduce per step.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the draw kernel (the
+largest single kernel of the step: n^2*B flop on f32 MFMA), timed with HIP events on the stream it
+runs on inside the timed region.  `cpu_baseline` is the oracle's NumPy/LAPACK restatement of the
+same step timed on this box's host cores (rank 0, N = 1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+GRID = 64
+N = GRID * GRID
+B = 4096
+DIMS = (50, 30, 15)  # 2d_examples.py hidden_dims / z_dim
+JITTER = 1.0e-3      # 2d_examples.py:503
+LR = 1.0e-3
+
+
+def grid_points():
+    g = np.arange(0, 1, 1 / GRID)
+    u, v = np.meshgrid(g, g)  # 2d_examples.py:562-564
+    return np.stack([u.ravel(), v.ravel()], 1).astype(np.float32)
+
+
+def bench_hyper(rng):
+    """(ls, var, sigma) from the reference's priors (vae.py:157-159) with ls clipped to [0.05, 1]:
+    InverseGamma(1, .1) has a heavy tail, and an f32 64x64-grid Gram matrix stops being positive
+    definite at jitter 1e-3 for ls >~ 3 (the reference diverges to NaN there — its committed 2-D
+    decoder is all-NaN).  The work per step does not depend on the values."""
+    from gp_vae_amd.gp import draw_hyper
+    ls, var, sigma = draw_hyper(rng)
+    return min(max(float(ls), 0.05), 1.0), float(var), float(sigma)
+
+
+def cpu_baseline(steps=3):
+    """The oracle's train_step (NumPy/SciPy, multi-threaded LAPACK) at the same sizes."""
+    from oracle import gpvae_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    rng = np.random.default_rng(0)
+    x = grid_points()
+    p = orc.init_params(rng, N, *DIMS, np.float32)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(a) for k, a in p.items()}
+    t_used = 0.0
+    done = 0
+    for t in range(1, steps + 1):
+        hyper = bench_hyper(rng)
+        E = rng.standard_normal((B, N), dtype=np.float32)
+        E2 = rng.standard_normal((B, N), dtype=np.float32)
+        ez = rng.standard_normal((B, DIMS[2]), dtype=np.float32)
+        t0 = time.perf_counter()
+        _, p, m, v = orc.train_step(p, m, v, t, x, hyper, E, E2, ez, LR, JITTER)
+        t_used += time.perf_counter() - t0
+        done += 1
+        if t_used > 25.0:
+            break
+    return {"value": B * done / t_used, "unit": "draws/s", "cores": int(cores), "kind": "port",
+            "sample": "%d full training steps (n=4096, B=4096, f32) of oracle.train_step, "
+                      "normals pre-generated, %.1f s" % (done, t_used)}
+
+
+def potrf_microbench(ops, x, batch=16, iters=3):
+    """Batched Cholesky TFLOP/s: `batch` Gram matrices with ls on a ladder."""
+    dev = x.device
+    ls = torch.linspace(0.05, 1.0, batch, device=dev)
+    var = torch.ones(batch, device=dev)
+    Kb = torch.empty((batch, N, N), device=dev)
+    info = None
+    times = []
+    for it in range(iters + 1):
+        ops.gram_se(x, x, var, ls, JITTER, out=Kb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        info = ops.potrf_(Kb, zero_upper=False, nan_on_fail=False)
+        e1.record()
+        torch.cuda.synchronize()
+        if it > 0:
+            times.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(times))
+    return {"batch": batch, "n": N, "ms": t * 1e3, "tflops": batch * N ** 3 / 3 / t / 1e12,
+            "frac_of_f32_mfma_peak": batch * N ** 3 / 3 / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "all_pd": bool((info == 0).all().item())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from gp_vae_amd import ops
+    from gp_vae_amd.vae import StepEngine, SVIState, init_params
+
+    dev = torch.device("cuda", local)
+    x = torch.tensor(grid_points(), device=dev)
+    eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, overlap=not args.no_overlap,
+                     hyper_sampler=bench_hyper)
+    state = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run([(0, i) for i in range(args.warmup)], state, train=True)
+    eng.draw_events = []
+    barrier()
+    t0 = time.perf_counter()
+    eng.run([(1, i) for i in range(args.steps)], state, train=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    draw_ms = float(np.mean([a.elapsed_time(b) for a, b in eng.draw_events])) if eng.draw_events else None
+    eng.draw_events = None
+    loss_last = float(eng.loss.item())
+
+    if rank == 0:
+        flop = float(N) * N * B  # algorithmic: n^2 * B  (draw TRMM)
+        achieved = flop / (draw_ms * 1e-3) / 1e12 if draw_ms else None
+        out = {
+            "metric": "GP-prior VAE training draws/sec at 64x64 grid",
+            "value": B * args.steps * world / elapsed,
+            "unit": "draws/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C3: 2D 64x64 grid (n=4096), exponential kernel, jitter 1e-3, "
+                                   "B=4096 GP draws/step/GPU, VAE 4096-50-30-15, Adam lr 1e-3, hyper-priors of vae.py:157-159 "
+                                   "(ls clipped to [0.05,1]); "
+                                   "full step gram+potrf+draw+ELBO fwd/bwd+Adam",
+                       "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
+                       "z_dim": DIMS[2], "parallelism": "dp%d" % world,
+                       "factor_stream_overlap": not args.no_overlap},
+            "roofline": {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
+                         "traffic": None, "avg_launch_ms": draw_ms, "flop_per_launch": flop},
+            "final_loss": loss_last,
+        }
+        out["cholesky"] = potrf_microbench(ops, x)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

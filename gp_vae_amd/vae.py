@@ -105,6 +105,7 @@ class StepEngine():
         self.ev_free = [torch.cuda.Event() for _ in range(2)]   # slot s has been consumed
         self.ev_copied = [torch.cuda.Event() for _ in range(2)]  # slot s's hyper upload is done
         self._issued = {}  # step key -> slot
+        self.draw_events = None  # bench.py: list of (start, end) HIP events around gpvae_draw
 
     # -- stage A: factor for one step (own stream) ---------------------------------------------------
     def _issue_factor(self, key, slot):
@@ -151,9 +152,15 @@ class StepEngine():
         K = self.Kbuf[slot]
         hd = self.hyper_dev[slot]
         lib = _lib.load()
+        if self.draw_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(main)
         check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
                              _p(self.E2), self.n, _p(hd[2:3]), None, 0, _p(self.Y), self.n),
               "gpvae_draw")
+        if self.draw_events is not None:
+            ev[1].record(main)
+            self.draw_events.append(ev)
         if self.overlap:
             self.ev_free[slot].record(main)
         ops.vae_elbo(state.params, self.Y, self.eps_z, (self.h0, self.h1, self.z), self.obs_sigma,
