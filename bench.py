@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--group", type=int, default=8, help="steps whose factors are built as one batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,7 +129,7 @@ def main():
     dev = torch.device("cuda", local)
     x = torch.tensor(grid_points(), device=dev)
     eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, overlap=not args.no_overlap,
-                     hyper_sampler=bench_hyper)
+                     hyper_sampler=bench_hyper, group=args.group)
     state = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
 
     def barrier():
@@ -174,7 +175,7 @@ def main():
                                    "full step gram+potrf+draw+ELBO fwd/bwd+Adam",
                        "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
                        "z_dim": DIMS[2], "parallelism": "dp%d" % world,
-                       "factor_stream_overlap": not args.no_overlap},
+                       "factor_stream_overlap": not args.no_overlap, "factor_group": args.group},
             "roofline": {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,

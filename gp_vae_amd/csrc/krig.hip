@@ -65,7 +65,8 @@ using namespace gpvae;
 
 extern "C" int64_t gpvae_krig_workspace_bytes(int dtype, int64_t n_obs, int64_t n_test) {
   const KrigWork w = krig_layout(n_obs, n_test);
-  return (w.a_elems + w.x_elems) * (dtype == GPVAE_F64 ? 8 : 4) + 256;
+  return (w.a_elems + w.x_elems) * (dtype == GPVAE_F64 ? 8 : 4) + 256 +
+         gpvae_potrf_workspace_bytes(dtype, n_obs, n_test + 1, 1);
 }
 
 extern "C" int gpvae_krig_predict(void *stream, int dtype, int d, int64_t n_obs, int64_t n_test,
@@ -105,8 +106,10 @@ extern "C" int gpvae_krig_predict(void *stream, int dtype, int d, int64_t n_obs,
     set_error("gpvae_krig_predict: hipMemcpyAsync(y_obs) failed");
     return -8;
   }
+  char *pw = X + (size_t)w.x_elems * es;
+  pw = (char *)(((uintptr_t)pw + 15) & ~(uintptr_t)15);
   rc = gpvae_potrf(stream, dtype, n_obs, 1, A, w.lda, w.a_elems, n_test + 1, X, w.lda, w.x_elems,
-                   info, 0, nullptr);
+                   info, 0, pw);
   if (rc) return rc;
   if (n_test > 0) {
     const unsigned blocks = (unsigned)cdiv(n_test, 4);

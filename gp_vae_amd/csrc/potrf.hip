@@ -150,7 +150,7 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, int vec,
-                                                               unsigned long long *stamps) {
+                                                               T *dwork, unsigned long long *stamps) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
   constexpr int NCH = Cfg::NCH, S = Cfg::S, PBK = Cfg::BK;
@@ -321,19 +321,27 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   STAMP(4);
 
   // ---- coalesced stores ---------------------------------------------------------------------------
-  for (int idx = tid; idx < (NCH + (blockIdx.x == 0 ? 1 : 0)) * NB * VPR; idx += NTHREADS) {
+  // The factored diagonal block is NOT written over D here: a workgroup of this launch that starts
+  // late (busy CUs, more workgroups than CUs) must still find the unfactored D in A.  L11 goes to
+  // the caller's scratch (dense 64x64 per diagonal block) and potrf_finalize_kernel puts it in place.
+  const int nst = (NCH + (blockIdx.x == 0 ? 1 : 0)) * NB * VPR;
+  T *l11 = dwork + ((int64_t)b * (vr.npad / NB) + c0 / NB) * (NB * NB);
+#pragma unroll 4
+  for (int idx = tid; idx < nst; idx += NTHREADS) {
     const int s = idx / VPR, j = (idx % VPR) * VEC;  // s < NCH*NB: chunk rows; beyond: L11 (block 0)
     const bool is_l11 = s >= NCH * NB;
     const int li = s - NCH * NB;
-    T *rp = is_l11 ? vr.ptr(c0 + li) : vr.ptr(rbase + s);
-    if (rp == nullptr) continue;
     V t = *reinterpret_cast<const V *>(is_l11 ? &Dm[li * S + j] : &Cw[s * S + j]);
     T *tp = reinterpret_cast<T *>(&t);
     if (is_l11) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e)
         if (j + e > li) tp[e] = T(0);  // clean upper triangle inside the diagonal block
+      *reinterpret_cast<V *>(&l11[li * NB + j]) = t;
+      continue;
     }
+    T *rp = vr.ptr(rbase + s);
+    if (rp == nullptr) continue;
     T *dst = rp + c0 + j;
     if (vcols) {
       *reinterpret_cast<V *>(dst) = t;
@@ -427,26 +435,30 @@ __global__ __launch_bounds__(NTHREADS) void potrf_syrk_kernel(VRows<T> vr, int64
 
 // ---- finalize: zero the strict upper triangle; NaN-fill failed matrices -------------------------------
 template <typename T>
-__global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_t n,
-                                      const int32_t *info, int flags) {
+__global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_t n, int64_t npad,
+                                      const T *dwork, const int32_t *info, int flags) {
   const int b = blockIdx.z;
   T *Ab = A + (int64_t)b * strideA;
   const bool failed = (flags & GPVAE_POTRF_NAN_ON_FAIL) && info[b] != 0;
   const bool zero_up = flags & GPVAE_POTRF_ZERO_UPPER;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const int64_t i0 = (int64_t)blockIdx.y * 64;
-  const int64_t i1 = (i0 + 64 < n) ? i0 + 64 : n;
-  if (!failed && (!zero_up || j <= i0)) return;  // nothing to do for this column strip
+  const int64_t i0 = (int64_t)blockIdx.y * NB;
+  const int64_t i1 = (i0 + NB < n) ? i0 + NB : n;
+  const bool in_diag = j >= i0 && j < i0 + NB;  // this column crosses the strip's diagonal block
+  if (!failed && !in_diag && (!zero_up || j < i0)) return;  // nothing to do for this column strip
+  const T *l11 = dwork + ((int64_t)b * (npad / NB) + blockIdx.y) * (NB * NB);
   for (int64_t i = i0; i < i1; ++i) {
     if (failed) Ab[i * lda + j] = dnan<T>();
+    else if (in_diag) Ab[i * lda + j] = l11[(i - i0) * NB + (j - i0)];  // L11 (upper part is zero)
     else if (j > i) Ab[i * lda + j] = T(0);
   }
 }
 
 template <typename T>
 static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
-                     int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags) {
+                     int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
+                     void *work) {
   constexpr int NCH = PanelCfg<T>::NCH;
   VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
   const int64_t Mv = vr.npad + mx;
@@ -463,7 +475,7 @@ static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda,
       const int64_t below = Mv - (c0 + NB);
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
       hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)nwg, (unsigned)batch),
-                         dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, vec, g_stamps);
+                         dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, vec, (T *)work, g_stamps);
     }
     if (kend < n) {
       const int64_t rt = cdiv(Mv - kend, SBM), ct = cdiv(n - kend, SBM);
@@ -471,11 +483,9 @@ static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda,
                          dim3(NTHREADS), 0, st, vr, strideA, strideX, cJ, kend, vec);
     }
   }
-  if (flags & (GPVAE_POTRF_ZERO_UPPER | GPVAE_POTRF_NAN_ON_FAIL)) {
-    hipLaunchKernelGGL((potrf_finalize_kernel<T>),
-                       dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(n, 64), (unsigned)batch),
-                       dim3(256), 0, st, (T *)A, lda, strideA, n, info, flags);
-  }
+  hipLaunchKernelGGL((potrf_finalize_kernel<T>),
+                     dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(n, NB), (unsigned)batch), dim3(256),
+                     0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info, flags);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
 }
@@ -487,14 +497,16 @@ using namespace gpvae;
 extern "C" void gpvae_dev_set_stamps(void *p) { gpvae::g_stamps = (unsigned long long *)p; }
 
 extern "C" int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch) {
-  (void)dtype; (void)n; (void)m_extra; (void)batch;
-  return 0;  // the factorisation is in place; kept in the ABI so a blocked variant may use scratch
+  (void)m_extra;
+  // one dense 64x64 block per diagonal block and matrix: the factored diagonal blocks wait here
+  // until the last launch copies them over A (see potrf_panel_kernel's store phase)
+  if (n <= 0 || batch <= 0) return 0;
+  return (int64_t)batch * round_up(n, NB) * NB * (dtype == GPVAE_F64 ? 8 : 4);
 }
 
 extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
                            int64_t strideA, int64_t m_extra, void *X, int64_t ldx,
                            int64_t strideX, int32_t *info, int flags, void *work) {
-  (void)work;
   GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_potrf: bad dtype %d", dtype);
   GPVAE_REQUIRE(n >= 0, 3, "gpvae_potrf: n < 0");
   GPVAE_REQUIRE(batch >= 0 && batch <= 65535, 4, "gpvae_potrf: batch out of range [0,65535]");
@@ -509,11 +521,14 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
     GPVAE_REQUIRE(batch == 1 || strideX >= m_extra * ldx, 11, "gpvae_potrf: strideX too small");
   }
   GPVAE_REQUIRE(info, 12, "gpvae_potrf: info is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 14,
+                "gpvae_potrf: work is NULL or not 16-byte aligned (gpvae_potrf_workspace_bytes)");
   GPVAE_REQUIRE(cdiv(round_up(n, NB) + m_extra, SBM) <= 65535, 3, "gpvae_potrf: too many rows");
   hipStream_t st = (hipStream_t)stream;
   if (m_extra == 0) X = nullptr;
   return dtype == GPVAE_F32
-             ? run_potrf<float>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info, flags)
+             ? run_potrf<float>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info, flags,
+                                work)
              : run_potrf<double>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info,
-                                 flags);
+                                 flags, work);
 }

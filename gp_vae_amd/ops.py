@@ -97,7 +97,7 @@ def gram_agg(pts, var, ls, jitter=1.0e-6):
     return K
 
 
-def potrf_(A, X=None, zero_upper=True, nan_on_fail=True):
+def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None):
     """In-place lower Cholesky of A [n,n] or [batch,n,n]; X ([.., m, n]) becomes X L^-T.
 
     Returns the int32 info tensor [batch] (device; 0 = ok, j = leading minor j not PD)."""
@@ -116,9 +116,12 @@ def potrf_(A, X=None, zero_upper=True, nan_on_fail=True):
     info = torch.empty((batch,), dtype=torch.int32, device=A.device)
     flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
     lib = _lib.load()
+    if work is None:
+        work = torch.empty(max(16, lib.gpvae_potrf_workspace_bytes(_dt(A), n, m, batch)),
+                           dtype=torch.uint8, device=A.device)
     check(lib.gpvae_potrf(_stream(), _dt(A), n, batch, _p(A3), A3.stride(1), A3.stride(0), m,
                           _p(X3), X3.stride(1) if m else 0, X3.stride(0) if m else 0, _p(info),
-                          flags, C.c_void_p(0)), "gpvae_potrf")
+                          flags, _p(work)), "gpvae_potrf")
     return info
 
 

@@ -68,12 +68,18 @@ def decoder_flat_from_list(params_list, dtype=None, device=None):
 
 
 class StepEngine():
-    """One training/evaluation step = gram -> potrf -> draw -> ELBO (-> all-reduce -> Adam)."""
+    """One training/evaluation step = gram -> potrf -> draw -> ELBO (-> all-reduce -> Adam).
+
+    The factors of the next `group` steps are independent of the network, so they are built as ONE
+    batched Gram + batched Cholesky launch sequence on a side stream (throughput mode of the panel
+    sweep instead of `group` latency-bound single factorisations), one group ahead of the
+    draw/ELBO/Adam chain; 2 x group factor slots live in HBM (group=8, n=4096, f32: 1 GiB)."""
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
-                 hyper_sampler=draw_hyper, overlap=True):
+                 hyper_sampler=draw_hyper, overlap=True, group=8):
         self.x = _as_device(x, dtype)
         self.n = self.x.shape[0]
+        self.d = self.x.shape[1] if self.x.dim() == 2 else 1
         self.h0, self.h1, self.z = dims
         self.B = batch_size
         self.lr = lr
@@ -85,11 +91,15 @@ class StepEngine():
         self.rank, self.world = dist_info()
         dev = self.x.device
         n, B = self.n, self.B
+        self.G = max(1, int(group))
         self.ld = (n + 3) // 4 * 4  # 16-byte aligned rows for the vector loads
-        self.Kbuf = [torch.empty((n, self.ld), dtype=dtype, device=dev) for _ in range(2)]
-        self.hyper_dev = [torch.empty(3, dtype=dtype, device=dev) for _ in range(2)]
-        self.hyper_pin = [torch.empty(3, dtype=dtype).pin_memory() for _ in range(2)]
-        self.info = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        G = self.G
+        self.Kbuf = [torch.empty((G, n, self.ld), dtype=dtype, device=dev) for _ in range(2)]
+        self.hyper_dev = [torch.empty((3, G), dtype=dtype, device=dev) for _ in range(2)]  # var|ls|sigma
+        self.hyper_pin = [torch.empty((3, G), dtype=dtype).pin_memory() for _ in range(2)]
+        self.info = [torch.zeros(G, dtype=torch.int32, device=dev) for _ in range(2)]
+        wbytes = _lib.load().gpvae_potrf_workspace_bytes(_dt(self.x), n, 0, G)
+        self.pwork = [torch.empty(max(16, wbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.E = torch.empty((B, n), dtype=dtype, device=dev)
         self.E2 = torch.empty((B, n), dtype=dtype, device=dev)
         self.Y = torch.empty((B, n), dtype=dtype, device=dev)
@@ -101,67 +111,60 @@ class StepEngine():
         self.work = ops.VaeWorkspace(B, n, self.h0, self.h1, self.z, dtype, dev)
         self.overlap = overlap
         self.s_gp = torch.cuda.Stream(device=dev) if overlap else None
-        self.ev_ready = [torch.cuda.Event() for _ in range(2)]  # factor of slot s is ready
-        self.ev_free = [torch.cuda.Event() for _ in range(2)]   # slot s has been consumed
+        self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # factors of group slot s are ready
+        self.ev_free = [torch.cuda.Event() for _ in range(2)]    # group slot s has been consumed
         self.ev_copied = [torch.cuda.Event() for _ in range(2)]  # slot s's hyper upload is done
-        self._issued = {}  # step key -> slot
         self.draw_events = None  # bench.py: list of (start, end) HIP events around gpvae_draw
 
-    # -- stage A: factor for one step (own stream) ---------------------------------------------------
-    def _issue_factor(self, key, slot):
-        ls, var, sigma = self.hyper_sampler(step_rng(self.seed, self.rank, key))
+    # -- stage A: the factors of one group of steps (own stream) ---------------------------------------
+    def _issue_factors(self, keys, slot):
+        g = len(keys)
         pin = self.hyper_pin[slot]
+        self.ev_copied[slot].synchronize()  # the staging block's previous upload has left the host
+        for i, key in enumerate(keys):
+            ls, var, sigma = self.hyper_sampler(step_rng(self.seed, self.rank, key))
+            pin[0, i], pin[1, i], pin[2, i] = float(var), float(ls), float(sigma)
+        for i in range(g, self.G):  # unused slots of a short last group: harmless values
+            pin[0, i], pin[1, i], pin[2, i] = 1.0, 1.0, 0.0
         stream = self.s_gp if self.overlap else torch.cuda.current_stream()
-        self.ev_copied[slot].synchronize()  # the staging triple's previous upload has left the host
-        pin[0], pin[1], pin[2] = float(var), float(ls), float(sigma)
         if self.overlap:
-            stream.wait_event(self.ev_free[slot])  # the draw that read this slot's factor is done
+            stream.wait_event(self.ev_free[slot])  # the draws that read this slot's factors are done
         with torch.cuda.stream(stream):
-            self.hyper_dev[slot].copy_(pin, non_blocking=True)
+            hd = self.hyper_dev[slot]
+            hd.copy_(pin, non_blocking=True)
             self.ev_copied[slot].record(stream)
-            self._gram_into(slot)
-            self._potrf(slot)
+            K = self.Kbuf[slot]
+            lib = _lib.load()
+            check(lib.gpvae_gram_se(_stream(), _dt(K), self.d, self.n, self.n, _p(self.x),
+                                    _p(self.x), g, _p(hd[0]), _p(hd[1]), float(self.jitter), _p(K),
+                                    self.ld, self.n * self.ld), "gpvae_gram_se")
+            # the draw masks the strict upper triangle itself: no zeroing / NaN-fill pass needed
+            check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
+                                  0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
+                  "gpvae_potrf")
             self.ev_ready[slot].record(stream)
-        self._issued[key] = slot
-
-    def _gram_into(self, slot):
-        hd = self.hyper_dev[slot]
-        K = self.Kbuf[slot]
-        lib = _lib.load()
-        check(lib.gpvae_gram_se(_stream(), _dt(K), self.x.shape[1] if self.x.dim() == 2 else 1,
-                                self.n, self.n, _p(self.x), _p(self.x), 1, _p(hd[0:1]), _p(hd[1:2]),
-                                float(self.jitter), _p(K), self.ld, self.n * self.ld),
-              "gpvae_gram_se")
-
-    def _potrf(self, slot):
-        K = self.Kbuf[slot]
-        lib = _lib.load()
-        # the draw masks the strict upper triangle itself: no zeroing / NaN-fill pass needed
-        check(lib.gpvae_potrf(_stream(), _dt(K), self.n, 1, _p(K), self.ld, self.n * self.ld, 0,
-                              C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, C.c_void_p(0)),
-              "gpvae_potrf")
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
-    def _consume(self, key, slot, state, train):
+    def _consume(self, key, slot, i, last_of_group, state, train):
         main = torch.cuda.current_stream()
-        if self.overlap:
+        if self.overlap and i == 0:
             main.wait_event(self.ev_ready[slot])
         ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
         ops.randn(None, out=self.E2, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 2))
         ops.randn(None, out=self.eps_z, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
-        K = self.Kbuf[slot]
-        hd = self.hyper_dev[slot]
+        K = self.Kbuf[slot][i]
+        sig = self.hyper_dev[slot][2, i:i + 1]
         lib = _lib.load()
         if self.draw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
         check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
-                             _p(self.E2), self.n, _p(hd[2:3]), None, 0, _p(self.Y), self.n),
+                             _p(self.E2), self.n, _p(sig), None, 0, _p(self.Y), self.n),
               "gpvae_draw")
         if self.draw_events is not None:
             ev[1].record(main)
             self.draw_events.append(ev)
-        if self.overlap:
+        if self.overlap and last_of_group:
             self.ev_free[slot].record(main)
         ops.vae_elbo(state.params, self.Y, self.eps_z, (self.h0, self.h1, self.z), self.obs_sigma,
                      grads=self.grads if train else None, loss=self.loss, work=self.work)
@@ -178,15 +181,17 @@ class StepEngine():
         keys = [tuple(k) for k in keys]
         if not keys:
             return self.loss_sum
+        groups = [keys[i:i + self.G] for i in range(0, len(keys), self.G)]
         if self.overlap:
             for s in range(2):
                 self.ev_free[s].record(torch.cuda.current_stream())
-        self._issue_factor(keys[0], 0)
-        for i, key in enumerate(keys):
-            slot = i & 1
-            if i + 1 < len(keys):
-                self._issue_factor(keys[i + 1], (i + 1) & 1)
-            self._consume(key, slot, state, train)
+        self._issue_factors(groups[0], 0)
+        for gi, grp in enumerate(groups):
+            slot = gi & 1
+            if gi + 1 < len(groups):
+                self._issue_factors(groups[gi + 1], (gi + 1) & 1)
+            for i, key in enumerate(grp):
+                self._consume(key, slot, i, i == len(grp) - 1, state, train)
         return self.loss_sum
 
 

@@ -66,8 +66,11 @@ int gpvae_gram_agg(void *stream, int dtype, int d, int64_t n_cells, int m, const
  * In place: the lower triangle of A[b] ([n, lda]) is overwritten by L with A = L L^T.
  * If m_extra > 0, X[b] ([m_extra, ldx]) is overwritten by X L^-T (the right-side triangular solve
  * the kriging path needs: rows of k_px and y^T) — the same panel sweep, no second pass over L.
+ * The strict upper triangle is not referenced, except that it is cleared inside the 64x64
+ * diagonal blocks (and everywhere with GPVAE_POTRF_ZERO_UPPER).
  * info[b] (int32): 0 = ok, j>0 = leading minor j not positive definite (LAPACK potrf).
- * work: gpvae_potrf_workspace_bytes() bytes (may be NULL when that is 0).                          */
+ * work: gpvae_potrf_workspace_bytes() bytes, 16-byte aligned (factored diagonal blocks are parked
+ * there until the last launch, so late workgroups of a panel launch never see a half-updated A).   */
 int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch);
 int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
                 int64_t strideA, int64_t m_extra, void *X, int64_t ldx, int64_t strideX,

@@ -62,7 +62,8 @@ def test_size_queries():
     assert lib.gpvae_vae_workspace_bytes(0, 100, n, h0, h1, z) >= 100 * n * 4
     assert lib.gpvae_vae_workspace_bytes(1, 100, n, h0, h1, z) >= 100 * n * 8
     assert lib.gpvae_krig_workspace_bytes(1, 100, 50) >= (100 * 100 + 51 * 100) * 8
-    assert lib.gpvae_potrf_workspace_bytes(0, 4096, 0, 32) == 0
+    assert lib.gpvae_potrf_workspace_bytes(0, 4096, 0, 32) == 32 * 4096 * 64 * 4
+    assert lib.gpvae_potrf_workspace_bytes(1, 100, 7, 2) == 2 * 128 * 64 * 8
 
 
 def test_cpu_tensors_are_refused_loudly():

@@ -160,6 +160,22 @@ def test_potrf_non_pd_batched_and_trailing_rows(ops, ndt, tdt, tol):
         assert torch.all(Abuf[:, n:] == 0) and torch.all(Xbuf[:, n:] == 0)  # padding untouched
 
 
+def test_potrf_more_workgroups_than_cus(ops):
+    """Regression: panel launches with more workgroups than the chip holds at once (320 > 256) —
+    late workgroups must still read the unfactored diagonal block."""
+    rng = np.random.default_rng(7)
+    n, batch = 1100, 64
+    x = dev(np.sort(rng.random(n)), torch.float32)
+    ls = torch.linspace(0.02, 0.2, batch, device=DEV)
+    K = ops.gram_se(x, x, torch.ones(batch, device=DEV), ls, 1e-3)
+    A = K.clone()
+    info = ops.potrf_(A)
+    assert int(info.abs().sum().item()) == 0
+    L = A.double()
+    err = torch.linalg.norm(L @ L.transpose(1, 2) - K.double(), dim=(1, 2)) / torch.linalg.norm(K.double(), dim=(1, 2))
+    assert err.max().item() < 2e-6, err.max().item()
+
+
 def test_potrf_full_size_backward_error(ops):
     x = dev(grid2(64), torch.float32)  # C3 size, script jitter (2d_examples.py:503)
     ls = torch.tensor([0.05, 0.3, 1.0], device=DEV)
