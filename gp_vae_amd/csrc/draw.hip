@@ -13,7 +13,7 @@ namespace gpvae {
 constexpr int DBM = 128;
 
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void draw_kernel(int64_t n, int64_t nb, const T *L,
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(int64_t n, int64_t nb, const T *L,
                                                         int64_t ldl, const T *E, int64_t lde,
                                                         const T *E2, int64_t lde2,
                                                         const T *sigma_p, T *F, int64_t ldf, T *Y,
@@ -22,10 +22,13 @@ __global__ __launch_bounds__(NTHREADS) void draw_kernel(int64_t n, int64_t nb, c
   using M = Mfma<T>;
   constexpr int DBK = TileK<T>::BK;
   constexpr int FR = 64 / M::TM;
-  constexpr int LD = DBM + LdsPad<T>::V;
+  constexpr int LD = DBM + KC_PAD;
   __shared__ __align__(16) T As[DBK * LD];
   __shared__ __align__(16) T Bs[DBK * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Plain round-robin placement already puts blocks b, b+8, ... (same column tile of L, row tiles
+  // 8 apart) on one XCD; a contiguous-run remap (guide T1) was measured 1.8x SLOWER here because it
+  // hands whole heavy column tiles to one XCD (the k range grows with the column index).
   const int ct = nct - 1 - (int)(blockIdx.x / nrt);  // heaviest column tiles first
   const int rt = (int)(blockIdx.x % nrt);
   const int64_t r0 = (int64_t)rt * DBM, c0 = (int64_t)ct * DBM;

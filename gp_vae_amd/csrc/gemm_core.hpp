@@ -24,8 +24,13 @@ template <> struct VecT<double> {
   using type = double2;
 };
 
-// LDS row padding (elements): keeps rows 16-byte aligned; transposing stores are <=2-way conflicts.
+// LDS row padding (elements) of an image filled by LoaderMC: rows stay 16-byte aligned for its
+// vector stores.
 template <typename T> struct LdsPad { static constexpr int V = 16 / sizeof(T); };
+// Row padding of an image filled ONLY by LoaderKC (transposing scalar stores): an odd stride makes
+// the 32 lanes of a store group (8 k-chunks x 4 rows) hit 32 different banks; fragment reads are
+// consecutive-lane, conflict free for any stride.
+constexpr int KC_PAD = 1;
 
 // ---- loader: source contiguous along K:  element(r, k) = rowptr[r][k] ------------------------------
 // ROWS x BK tile; per-thread row pointers are fixed over the k loop.  A row that does not exist
@@ -62,10 +67,16 @@ struct LoaderKC {
     (void)rowptr(0, dummy);
     rowg_min = dummy;
   }
-  // loads columns [k0, k0+BK) clipped to [kbeg, kend)
+  // loads columns [k0, k0+BK) clipped to [kbeg, kend).  The fast path only ISSUES the loads: the
+  // registers are not touched again until store(), so the wait for them lands after the MFMAs of
+  // the tile in flight (masking of absent rows / the triangle happens in store()).
+  int64_t k0_;
+  bool fast_;
   __device__ __forceinline__ void load(int64_t k0, int64_t kbeg, int64_t kend, bool vec, int tid) {
     const bool interior = k0 >= kbeg && k0 + BK <= kend;  // wave-uniform
-    if (vec && interior) {
+    k0_ = k0;
+    fast_ = vec && interior;
+    if (fast_) {
 #pragma unroll
       for (int p = 0; p < NV; ++p) {
         const int v = tid + p * NTHREADS;
@@ -73,7 +84,7 @@ struct LoaderKC {
         const V t = *reinterpret_cast<const V *>(rp[p] + k);
         const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) regs[p][e] = ok[p] ? tp[e] : T(0);
+        for (int e = 0; e < VEC; ++e) regs[p][e] = tp[e];
       }
     } else {
 #pragma unroll
@@ -87,26 +98,22 @@ struct LoaderKC {
         }
       }
     }
-    if (TRI && k0 + BK - 1 > rowg_min) {
-#pragma unroll
-      for (int p = 0; p < NV; ++p) {
-        const int v = tid + p * NTHREADS;
-        const int64_t k = k0 + (v % VPR) * VEC;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (k + e > rowg[p]) regs[p][e] = T(0);
-      }
-    }
   }
   // lds: [BK][LD] k-major image;  NEG stores the negated tile (C - A B^T as an MFMA accumulate)
   template <int LD, bool NEG = false> __device__ __forceinline__ void store(T *lds, int tid) const {
+    const bool tri = TRI && (k0_ + BK - 1 > rowg_min);  // wave-uniform: tile reaches the diagonal
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int v = tid + p * NTHREADS;
       const int r = v / VPR, kc = (v % VPR) * VEC;
       if (EXACT || r < ROWS) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) lds[(kc + e) * LD + r] = NEG ? -regs[p][e] : regs[p][e];
+        for (int e = 0; e < VEC; ++e) {
+          T val = regs[p][e];
+          if (!ok[p]) val = T(0);
+          if (TRI && tri && (k0_ + kc + e > rowg[p])) val = T(0);
+          lds[(kc + e) * LD + r] = NEG ? -val : val;
+        }
       }
     }
   }
@@ -206,12 +213,14 @@ __device__ __forceinline__ void mma_ktile(const T *As, const T *Bs, int am0, int
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) b[g][fn] = bp[(g0 + g) * M::KI * LDB + fn * M::TM];
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the group's reads ahead of its MFMAs
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = M::mma(a[g][fm], b[g][fn], acc[fm][fn]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   using Cfg = PanelCfg<T>;
   constexpr int NCH = Cfg::NCH, S = Cfg::S, PBK = Cfg::BK;
   constexpr int SROWS = NB + NB * NCH;              // stacked rows: diagonal block + chunks
-  constexpr int LDT = SROWS + LdsPad<T>::V;         // k-major staging stride
+  constexpr int LDT = SROWS + KC_PAD;               // k-major staging stride (odd)
   constexpr int RPW = 16 * NCH;                     // chunk rows per wave in the GEMM phase
   constexpr int FM = RPW / M::TM;                   // = 2 for both types
   constexpr int FN = NB / M::TM;                    // 2 (f32) / 4 (f64)
@@ -360,13 +360,13 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 constexpr int SBM = 128;
 
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void potrf_syrk_kernel(VRows<T> vr, int64_t strideA,
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_kernel(VRows<T> vr, int64_t strideA,
                                                               int64_t strideX, int64_t cJ,
                                                               int64_t kend, int vec) {
   using M = Mfma<T>;
   constexpr int SBK = TileK<T>::BK;
   constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
-  constexpr int LD = SBM + LdsPad<T>::V;
+  constexpr int LD = SBM + KC_PAD;
   if (blockIdx.x < blockIdx.y) return;
   __shared__ __align__(16) T As[SBK * LD];
   __shared__ __align__(16) T Bs[SBK * LD];

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
   constexpr int FM = 32 / M::TM;  // wave tile 32 x 64
   constexpr int FN = 64 / M::TM;
-  constexpr int LDA = GBM + LdsPad<T>::V, LDB = GBN + LdsPad<T>::V;
+  constexpr int LDA = GBM + (AKC ? KC_PAD : LdsPad<T>::V), LDB = GBN + (BKC ? KC_PAD : LdsPad<T>::V);
   __shared__ __align__(16) T As[GBK * LDA];
   __shared__ __align__(16) T Bs[GBK * LDB];
   __shared__ T red[4];

@@ -17,7 +17,7 @@ for _ in range(3):
     ops.potrf_(K, zero_upper=False, nan_on_fail=False)
     ops.draw(K, E, E2, 0.1)
 torch.cuda.synchronize()
-nb = int(os.environ.get("NBATCH", "8"))
+nb = int(os.environ.get("NBATCH", "16"))
 Kb = torch.empty((nb, n, n), device=dev)
 lsb = torch.linspace(0.05, 1.0, nb, device=dev); vb = torch.ones(nb, device=dev)
 for _ in range(2):
