@@ -12,19 +12,17 @@ namespace gpvae {
 
 constexpr int DBM = 128;
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(int64_t n, int64_t nb, const T *L,
-                                                        int64_t ldl, const T *E, int64_t lde,
-                                                        const T *E2, int64_t lde2,
-                                                        const T *sigma_p, T *F, int64_t ldf, T *Y,
-                                                        int64_t ldy, int nrt, int nct, int vec_e,
-                                                        int vec_l) {
+// VECM: L and E rows are 16-byte aligned (base and leading dimension) -> 16-byte loads.
+template <typename T, bool VECM>
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
+    int64_t n, int64_t nb, const T *L, int64_t ldl, const T *E, int64_t lde, const T *E2,
+    int64_t lde2, const T *sigma_p, T *F, int64_t ldf, T *Y, int64_t ldy, int nrt, int nct) {
   using M = Mfma<T>;
   constexpr int DBK = TileK<T>::BK;
   constexpr int FR = 64 / M::TM;
-  constexpr int LD = DBM + KC_PAD;
-  __shared__ __align__(16) T As[DBK * LD];
-  __shared__ __align__(16) T Bs[DBK * LD];
+  constexpr int LD = DBK + RmPad<T>::V;  // row-major images [128][LD]
+  __shared__ __align__(16) T As[DBM * LD];
+  __shared__ __align__(16) T Bs[DBM * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Plain round-robin placement already puts blocks b, b+8, ... (same column tile of L, row tiles
   // 8 apart) on one XCD; a contiguous-run remap (guide T1) was measured 1.8x SLOWER here because it
@@ -34,8 +32,8 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
   const int64_t r0 = (int64_t)rt * DBM, c0 = (int64_t)ct * DBM;
   const int64_t kend = (c0 + DBM < n) ? c0 + DBM : n;
 
-  LoaderKC<T, DBM, DBK> la;
-  LoaderKC<T, DBM, DBK, true> lb;
+  LoaderKC<T, DBM, DBK, VECM> la;
+  LoaderKC<T, DBM, DBK, VECM, true> lb;
   la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return (r0 + s < nb) ? E + (r0 + s) * lde : nullptr; }, E, tid);
   lb.init([&](int s, int64_t &rg) -> const T * { rg = c0 + s; return (c0 + s < n) ? L + (c0 + s) * ldl : nullptr; }, L, tid);
 
@@ -43,25 +41,15 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
   zero_acc<T, FR, FR>(acc);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  la.load(0, 0, kend, vec_e, tid);
-  lb.load(0, 0, kend, vec_l, tid);
-  la.template store<LD>(As, tid);
-  lb.template store<LD>(Bs, tid);
-  __syncthreads();
-  for (int64_t k = 0; k < kend; k += DBK) {
-    const bool more = k + DBK < kend;
-    if (more) {
-      la.load(k + DBK, 0, kend, vec_e, tid);
-      lb.load(k + DBK, 0, kend, vec_l, tid);
-    }
-    mma_ktile<T, FR, FR, DBK, LD, LD>(As, Bs, wm, wn, lane, acc);
-    __syncthreads();
-    if (more) {
-      la.template store<LD>(As, tid);
-      lb.template store<LD>(Bs, tid);
-      __syncthreads();
-    }
-  }
+  int64_t kfast = la.fast_end(kend);
+  if (lb.fast_end(kend) < kfast) kfast = lb.fast_end(kend);
+  kloop_kc<DBK>(
+      0, kend, kfast,
+      [&](int64_t k) { la.load(k, kend, tid); lb.load(k, kend, tid); },
+      [&]() { la.template store<LD>(As, tid); lb.template store<LD>(Bs, tid); },
+      [&](int64_t k) { la.load_fast(k); lb.load_fast(k); },
+      [&]() { la.template store_fast<LD>(As, tid); lb.template store_fast<LD>(Bs, tid); },
+      [&]() { mma_ktile<T, FR, FR, DBK, true, LD, true, LD>(As, Bs, wm, wn, lane, acc); });
   const T sigma = (E2 != nullptr) ? sigma_p[0] : T(0);
 #pragma unroll
   for (int fm = 0; fm < FR; ++fm) {
@@ -179,16 +167,20 @@ extern "C" int gpvae_draw(void *stream, int dtype, int64_t n, int64_t nb, const 
   const int64_t nrt = cdiv(nb, DBM), nct = cdiv(n, DBM);
   GPVAE_REQUIRE(nrt * nct < (int64_t)1 << 31, 4, "gpvae_draw: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GPVAE_F32)
-    hipLaunchKernelGGL((draw_kernel<float>), dim3((unsigned)(nrt * nct)), dim3(NTHREADS), 0, st, n,
-                       nb, (const float *)L, ldl, (const float *)E, lde, (const float *)E2, lde2,
-                       (const float *)sigma, (float *)F, ldf, (float *)Y, ldy, (int)nrt, (int)nct,
-                       (int)kc_vec_ok<float>(E, lde), (int)kc_vec_ok<float>(L, ldl));
-  else
-    hipLaunchKernelGGL((draw_kernel<double>), dim3((unsigned)(nrt * nct)), dim3(NTHREADS), 0, st, n,
-                       nb, (const double *)L, ldl, (const double *)E, lde, (const double *)E2, lde2,
-                       (const double *)sigma, (double *)F, ldf, (double *)Y, ldy, (int)nrt,
-                       (int)nct, (int)kc_vec_ok<double>(E, lde), (int)kc_vec_ok<double>(L, ldl));
+  auto launch = [&](auto tag, auto vecm) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((draw_kernel<T, decltype(vecm)::value>), dim3((unsigned)(nrt * nct)),
+                       dim3(NTHREADS), 0, st, n, nb, (const T *)L, ldl, (const T *)E, lde,
+                       (const T *)E2, lde2, (const T *)sigma, (T *)F, ldf, (T *)Y, ldy, (int)nrt,
+                       (int)nct);
+  };
+  if (dtype == GPVAE_F32) {
+    if (kc_vec_ok<float>(E, lde) && kc_vec_ok<float>(L, ldl)) launch(float{}, std::true_type{});
+    else launch(float{}, std::false_type{});
+  } else {
+    if (kc_vec_ok<double>(E, lde) && kc_vec_ok<double>(L, ldl)) launch(double{}, std::true_type{});
+    else launch(double{}, std::false_type{});
+  }
   GPVAE_CHECK_LAUNCH("gpvae_draw");
   return 0;
 }

@@ -1,12 +1,24 @@
 // gemm_core.hpp — building blocks of the f32/f64 MFMA tile GEMMs used by potrf, draw, krig, vae.
 //
 // Shape of every tile product: 256 threads (4 waves); operand tiles are staged global -> registers
-// -> LDS in a k-major image  As[k][row]  (row contiguous), so a wave's MFMA fragment read
-// (lane l needs A[row = l % TM][k = l / TM]) is one conflict-free scalar LDS read with consecutive
-// lanes on consecutive addresses.  f32 MFMA (v_mfma_f32_32x32x2_f32) runs at 64 cycles per
-// instruction, so one LDS read per operand per MFMA is far from the LDS limit
-// (cdna_hip_programming.md §3 "FP32-input MFMA").  The next k-tile's global loads are issued before
-// the current tile's MFMAs (register-staged double buffering, guide §6 G15).
+// -> LDS, the next k-tile's global loads issued before the current tile's MFMAs (register-staged
+// double buffering, guide §6 G15).
+//
+// What bounds these kernels (measured, tools/ub_mfma_valu.hip): on gfx950 an f32 MFMA occupies the
+// SIMD's vector ALU — v_mfma_f32_32x32x2_f32 takes 64 cycles and NO other VALU instruction of
+// either resident wave issues meanwhile (one wave streaming MFMAs + one wave streaming v_add: the
+// times add up exactly; same inside one wave).  So time = 64 * #MFMA + ~4..8 * #VALU per SIMD and
+// the only thing to optimise is the number of non-MFMA vector instructions per MFMA.  Hence two
+// LDS images:
+//   RM (row-major)  img[row][BK + RM_PAD]: filled by LoaderKC (source contiguous along k) with
+//       16-byte ds_writes, no transpose; a fragment read is ONE 16-byte ds_read per 4 (f32) /
+//       2 (f64) k-steps with a compile-time offset from one base register — zero address VALU.
+//       The k values of a chunk of 8 are dealt to the MFMA lane groups as k = 8c + KV*g + j
+//       (g = lane / TM, j = k-step inside the chunk); any assignment is valid as long as both
+//       operands use the same one.  Row stride 36 dwords: the 16 lanes of a 16-byte access phase
+//       land on 16 distinct 4-bank groups.
+//   KM (k-major)  img[k][rows + pad]: filled by LoaderMC (source contiguous along rows);
+//       scalar fragment reads, consecutive lanes on consecutive addresses.
 #pragma once
 #include "common.hpp"
 
@@ -27,33 +39,72 @@ template <> struct VecT<double> {
 // LDS row padding (elements) of an image filled by LoaderMC: rows stay 16-byte aligned for its
 // vector stores.
 template <typename T> struct LdsPad { static constexpr int V = 16 / sizeof(T); };
-// Row padding of an image filled ONLY by LoaderKC (transposing scalar stores): an odd stride makes
-// the 32 lanes of a store group (8 k-chunks x 4 rows) hit 32 different banks; fragment reads are
-// consecutive-lane, conflict free for any stride.
-constexpr int KC_PAD = 1;
+// Row padding (elements) of a row-major image: stride BK + RM_PAD = 36 dwords for BK = 32 f32 /
+// 16 f64.
+template <typename T> struct RmPad { static constexpr int V = 16 / sizeof(T); };
+
+// 16-byte buffer load: scalar resource (base address) + per-lane 32-bit byte offset + SCALAR byte
+// offset -> the k advance of a loop costs one s_add and no vector instruction.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ i32x4_t raw_buffer_load_b128(i32x4_t rsrc, int voffset, int soffset,
+                                        int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+// a value the program knows to be wave-uniform, moved to scalar registers (the compiler treats the
+// results of block-wide votes and anything derived from them as divergent)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ i32x4_t make_buffer_rsrc(const void *p) {
+  const uint64_t a = (uint64_t)uniform64((int64_t)reinterpret_cast<uint64_t>(p));
+  i32x4_t r;
+  r[0] = (int)(uint32_t)a;
+  r[1] = (int)(uint32_t)(a >> 32);  // stride 0: raw buffer
+  r[2] = -1;                        // num_records: no range check wanted
+  r[3] = 0x00020000;                // gfx9 raw-buffer dword 3 (32-bit data format)
+  return r;
+}
 
 // ---- loader: source contiguous along K:  element(r, k) = rowptr[r][k] ------------------------------
-// ROWS x BK tile; per-thread row pointers are fixed over the k loop.  A row that does not exist
-// reads zero: its pointer is replaced by `safe` (any row that can be read over the same k range)
-// and the value is discarded with a select, so the common path has no divergent branch.
-// `vec` (wave-uniform): every row pointer and k0 are 16-byte aligned => one 16-byte load per
-// vector.  TRI: additionally zero elements with k > rowg (global row index) — the draw kernel's
-// lower-triangle mask, only evaluated on k-tiles that reach the diagonal.
-template <typename T, int ROWS, int BK, bool TRI = false>
+// ROWS x BK tile; per-thread row pointers are fixed over the k loop.  Two paths:
+//   generic  load()/store(): any row set (a row that does not exist reads through `safe` and is
+//       zeroed), ragged end of the k range (clamped address, zeroed), TRI mask (zero k > global
+//       row, the draw kernel's lower-triangle mask).  Branch-free loads: nothing touches the
+//       registers until store(), so the wait lands after the MFMAs of the tile in flight.
+//   fast  load_fast()/store_fast(): NO vector-ALU instruction at all (see the header: a VALU
+//       instruction in this phase would wait for the partner wave's whole MFMA phase).  Loads are
+//       buffer_load_dwordx4 with a scalar resource (tile origin), a loop-invariant 32-bit per-lane
+//       byte offset and the k offset in a scalar register; stores are bare ds_write_b128.  Usable
+//       for a k-tile when fast_ok (VECM, every row present and within 2 GiB of the first row) and
+//       the tile needs no masking: k0 + BK <= fast_end(kend).
+//   VECM (template): all row pointers and k0 are 16-byte aligned (lda % VEC == 0, aligned base);
+//       otherwise VEC scalar loads.  NOTE: in VECM mode the last vector of a row may read up to
+//       round_up(kend, VEC) <= lda: the buffer must span rows * lda elements.
+template <typename T, int ROWS, int BK, bool VECM, bool TRI = false>
 struct LoaderKC {
   static constexpr int VEC = VecT<T>::N;
   static constexpr int VPR = BK / VEC;  // vectors per row
   static constexpr int NV = (ROWS * VPR + NTHREADS - 1) / NTHREADS;
   static constexpr bool EXACT = (ROWS * VPR) % NTHREADS == 0;
   using V = typename VecT<T>::type;
-  const T *rp[NV];
+  const T *rp[NV];   // row pointer + this thread's k offset inside a tile
+  int off[NV];       // the same as a byte offset from the first row of the tile (fast path)
+  i32x4_t rsrc;      // wave-uniform buffer resource: first row of the tile
   bool ok[NV];
   int64_t rowg[NV];
   int64_t rowg_min;  // smallest global row of the tile (TRI)
+  bool all_ok;       // wave-uniform: every row of the tile exists
+  bool fast_ok;      // wave-uniform: the fast path may be used
+  int64_t k0_, kend_;
   T regs[NV][VEC];
 
   template <class RowPtr>
   __device__ __forceinline__ void init(const RowPtr &rowptr, const T *safe, int tid) {
+    int64_t rg0;
+    const T *base = rowptr(0, rg0);
+    rowg_min = rg0;
+    rsrc = make_buffer_rsrc(base);
+    int mine = 1, fits = 1;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int v = tid + p * NTHREADS;
@@ -61,26 +112,57 @@ struct LoaderKC {
       rowg[p] = 0;
       const T *q = (EXACT || r < ROWS) ? rowptr(r, rowg[p]) : nullptr;
       ok[p] = q != nullptr;
-      rp[p] = ok[p] ? q : safe;
+      rp[p] = (ok[p] ? q : safe) + (v % VPR) * VEC;
+      const int64_t d = reinterpret_cast<const char *>(rp[p]) - reinterpret_cast<const char *>(base);
+      off[p] = (int)d;
+      if (EXACT || r < ROWS) {
+        if (!ok[p]) mine = 0;
+        if (d < 0 || d >= ((int64_t)1 << 31)) fits = 0;
+      }
     }
-    int64_t dummy;
-    (void)rowptr(0, dummy);
-    rowg_min = dummy;
+    // every thread of the block calls init
+    all_ok = __syncthreads_and(mine) != 0;
+    fast_ok = __syncthreads_and(fits) != 0 && all_ok && VECM && EXACT && base != nullptr;
   }
-  // loads columns [k0, k0+BK) clipped to [kbeg, kend).  The fast path only ISSUES the loads: the
-  // registers are not touched again until store(), so the wait for them lands after the MFMAs of
-  // the tile in flight (masking of absent rows / the triangle happens in store()).
-  int64_t k0_;
-  bool fast_;
-  __device__ __forceinline__ void load(int64_t k0, int64_t kbeg, int64_t kend, bool vec, int tid) {
-    const bool interior = k0 >= kbeg && k0 + BK <= kend;  // wave-uniform
+  // k-tiles [k0, k0+BK) with k0 + BK <= fast_end(kend) may use the fast path
+  __device__ __forceinline__ int64_t fast_end(int64_t kend) const {
+    if (!fast_ok || kend * (int64_t)sizeof(T) >= ((int64_t)1 << 31)) return INT64_MIN;
+    if (TRI && rowg_min + 1 < kend) return rowg_min + 1;  // tiles that stay at or below the diagonal
+    return kend;
+  }
+  __device__ __forceinline__ void load_fast(int64_t k0) {
+    const int soff = (int)(k0 * (int64_t)sizeof(T));  // scalar
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const i32x4_t t = raw_buffer_load_b128(rsrc, off[p], soff, 0);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) regs[p][e] = tp[e];
+    }
+  }
+  template <int LD> __device__ __forceinline__ void store_fast(T *lds, int tid) const {
+    static_assert(LD % VEC == 0, "row-major image rows must stay 16-byte aligned");
+    T *dst = lds + (tid / VPR) * LD + (tid % VPR) * VEC;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      V t;
+      T *tp = reinterpret_cast<T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tp[e] = regs[p][e];
+      *reinterpret_cast<V *>(dst + p * (NTHREADS / VPR) * LD) = t;
+    }
+  }
+  // issues the loads of columns [k0, k0+BK); columns >= kend are zeroed later (k0 < kend)
+  __device__ __forceinline__ void load(int64_t k0, int64_t kend, int tid) {
     k0_ = k0;
-    fast_ = vec && interior;
-    if (fast_) {
+    kend_ = kend;
+    if constexpr (VECM) {
+      const int64_t klast = (kend - 1) & ~(int64_t)(VEC - 1);  // last vector that starts < kend
 #pragma unroll
       for (int p = 0; p < NV; ++p) {
-        const int v = tid + p * NTHREADS;
-        const int64_t k = k0 + (v % VPR) * VEC;
+        const int kc = ((tid + p * NTHREADS) % VPR) * VEC;
+        int64_t k = k0;
+        if (k0 + BK > kend) k = (k0 + kc <= klast) ? k0 : klast - kc;  // uniform test, rare
         const V t = *reinterpret_cast<const V *>(rp[p] + k);
         const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
@@ -89,31 +171,34 @@ struct LoaderKC {
     } else {
 #pragma unroll
       for (int p = 0; p < NV; ++p) {
-        const int v = tid + p * NTHREADS;
-        const int64_t k = k0 + (v % VPR) * VEC;
+        const int kc = ((tid + p * NTHREADS) % VPR) * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const bool in = ok[p] && k + e >= kbeg && k + e < kend;
-          regs[p][e] = in ? rp[p][in ? k + e : kbeg] : T(0);
+          int64_t k = k0 + e;
+          if (k0 + BK > kend) k = (k0 + kc + e < kend) ? k0 + e : kend - 1 - kc;
+          regs[p][e] = rp[p][k];
         }
       }
     }
   }
-  // lds: [BK][LD] k-major image;  NEG stores the negated tile (C - A B^T as an MFMA accumulate)
-  template <int LD, bool NEG = false> __device__ __forceinline__ void store(T *lds, int tid) const {
-    const bool tri = TRI && (k0_ + BK - 1 > rowg_min);  // wave-uniform: tile reaches the diagonal
+  // lds: [ROWS][LD] row-major image (LD = BK + RmPad), masked as described above
+  template <int LD> __device__ __forceinline__ void store(T *lds, int tid) const {
+    static_assert(LD % VEC == 0, "row-major image rows must stay 16-byte aligned");
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
       const int v = tid + p * NTHREADS;
       const int r = v / VPR, kc = (v % VPR) * VEC;
       if (EXACT || r < ROWS) {
+        V t;
+        T *tp = reinterpret_cast<T *>(&t);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
+          const int64_t k = k0_ + kc + e;
           T val = regs[p][e];
-          if (!ok[p]) val = T(0);
-          if (TRI && tri && (k0_ + kc + e > rowg[p])) val = T(0);
-          lds[(kc + e) * LD + r] = NEG ? -val : val;
+          if (!ok[p] || k >= kend_ || (TRI && k > rowg[p])) val = T(0);
+          tp[e] = val;
         }
+        *reinterpret_cast<V *>(lds + r * LD + kc) = t;
       }
     }
   }
@@ -191,36 +276,105 @@ struct LoaderMC {
 };
 
 // ---- MFMA over one staged k-tile -------------------------------------------------------------------
-// acc[fm][fn] += A[am0 + fm*TM ..][k] * B[k][bn0 + fn*TM ..], k over the BK rows of the LDS images.
-// Fragments are read in groups of up to 8 k-steps BEFORE the group's MFMAs, so the LDS latency is
-// paid once per group instead of once per k-step (hipcc otherwise waits lgkmcnt(0) per step).
-template <typename T, int FM, int FN, int BK, int LDA, int LDB>
+// acc[fm][fn] += A[am0 + fm*TM ..][k] * B[k][bn0 + fn*TM ..], k over the BK columns of the LDS images.
+// ARM / BRM: the operand's image is row-major (LoaderKC) rather than k-major (LoaderMC); LDA / LDB
+// are the image strides.  k-steps come in chunks of 8 k values: lane group g = lane / TM holds
+// k = 8c + KV*g + j at step j of chunk c (KV = 4 f32, 2 f64), the same for both operands.
+// All fragment reads of the tile are issued before its first MFMA (the counters release the MFMAs
+// chunk by chunk), so LDS latency is paid once per tile.
+template <typename T, int FM, int FN, int BK, bool ARM, int LDA, bool BRM, int LDB>
 __device__ __forceinline__ void mma_ktile(const T *As, const T *Bs, int am0, int bn0, int lane,
                                           typename Mfma<T>::acc_t (&acc)[FM][FN]) {
   using M = Mfma<T>;
-  constexpr int KS = BK / M::KI;
-  constexpr int G = KS < 8 ? KS : 8;
-  const int lr = lane % M::TM, kg = lane / M::TM;
-  const T *ap = As + kg * LDA + am0 + lr;
-  const T *bp = Bs + kg * LDB + bn0 + lr;
+  using V = typename VecT<T>::type;
+  constexpr int KV = VecT<T>::N;
+  constexpr int NG = 64 / M::TM;       // lane groups = k values per MFMA step (M::KI)
+  constexpr int CK = NG * KV;          // k values per chunk (8)
+  constexpr int CH = BK / CK;
+  static_assert(NG == M::KI && BK % CK == 0, "chunked k mapping");
+  const int lr = lane % M::TM, g = lane / M::TM;
+  const T *ap = ARM ? As + (am0 + lr) * LDA + g * KV : As + (g * KV) * LDA + am0 + lr;
+  const T *bp = BRM ? Bs + (bn0 + lr) * LDB + g * KV : Bs + (g * KV) * LDB + bn0 + lr;
+  T a[CH][FM][KV], b[CH][FN][KV];
 #pragma unroll
-  for (int g0 = 0; g0 < KS; g0 += G) {
-    T a[G][FM], b[G][FN];
+  for (int c = 0; c < CH; ++c) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int fm = 0; fm < FM; ++fm) {
+      if constexpr (ARM) {
+        const V t = *reinterpret_cast<const V *>(ap + fm * M::TM * LDA + c * CK);
+        const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) a[g][fm] = ap[(g0 + g) * M::KI * LDA + fm * M::TM];
+        for (int j = 0; j < KV; ++j) a[c][fm][j] = tp[j];
+      } else {
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) b[g][fn] = bp[(g0 + g) * M::KI * LDB + fn * M::TM];
+        for (int j = 0; j < KV; ++j) a[c][fm][j] = ap[(c * CK + j) * LDA + fm * M::TM];
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the group's reads ahead of its MFMAs
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int fn = 0; fn < FN; ++fn) {
+      if constexpr (BRM) {
+        const V t = *reinterpret_cast<const V *>(bp + fn * M::TM * LDB + c * CK);
+        const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+        for (int j = 0; j < KV; ++j) b[c][fn][j] = tp[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < KV; ++j) b[c][fn][j] = bp[(c * CK + j) * LDB + fn * M::TM];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // reads ahead of the MFMAs
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int j = 0; j < KV; ++j)
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = M::mma(a[g][fm], b[g][fn], acc[fm][fn]);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = M::mma(a[c][fm][j], b[c][fn][j], acc[fm][fn]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- the k loop of a product whose operands both come through LoaderKC ------------------------------
+// Tiles k = kbeg, kbeg + BK, ... < kend (kbeg < kend).  `stage` stores the loaded tile(s) into LDS
+// (generic or fast path), `mma` runs the MFMAs of the staged tile.  Leading tiles that every loader
+// can take on its fast path run in a loop of their own that holds no VALU instruction besides the
+// MFMAs; the remaining (masked / ragged) tiles run through the generic path.
+template <int BK, class LoadG, class StoreG, class LoadF, class StoreF, class MmaF>
+__device__ __forceinline__ void kloop_kc(int64_t kbeg, int64_t kend, int64_t kfast, const LoadG &load_g,
+                                         const StoreG &store_g, const LoadF &load_f,
+                                         const StoreF &store_f, const MmaF &mma) {
+  kbeg = uniform64(kbeg);  // loop control on the scalar ALU
+  kend = uniform64(kend);
+  kfast = uniform64(kfast);
+  int64_t k = kbeg;
+  if (k + BK <= kfast) {
+    load_f(k);
+    store_f();
+  } else {
+    load_g(k);
+    store_g();
+  }
+  __syncthreads();
+  // tile k staged, tile k + BK fast.  A 32-bit trip count: gfx9 has no scalar 64-bit ordered
+  // compare, a 64-bit loop test would put a VALU compare into the loop.
+  const int nfast = (kfast - kbeg >= 2 * BK) ? (int)((kfast - kbeg) / BK) - 1 : 0;
+  for (int i = 0; i < nfast; ++i, k += BK) {
+    load_f(k + BK);
+    mma();
+    __syncthreads();
+    store_f();
+    __syncthreads();
+  }
+  for (; k < kend; k += BK) {
+    const bool more = k + BK < kend;
+    if (more) load_g(k + BK);
+    mma();
+    __syncthreads();
+    if (more) {
+      store_g();
+      __syncthreads();
+    }
   }
 }
 

@@ -146,16 +146,16 @@ __device__ __forceinline__ int tri_rows(T (&x)[NB], T *Lrow, T *rdiag, int lane,
   return fail;
 }
 
-template <typename T>
+template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
-                                                               int64_t cJ, int32_t *info, int vec,
-                                                               T *dwork, unsigned long long *stamps) {
+                                                               int64_t cJ, int32_t *info, T *dwork,
+                                                               unsigned long long *stamps) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
   constexpr int NCH = Cfg::NCH, S = Cfg::S, PBK = Cfg::BK;
   constexpr int SROWS = NB + NB * NCH;              // stacked rows: diagonal block + chunks
-  constexpr int LDT = SROWS + KC_PAD;               // k-major staging stride (odd)
+  constexpr int LDT = PBK + RmPad<T>::V;            // row-major staging image [SROWS][LDT]
   constexpr int RPW = 16 * NCH;                     // chunk rows per wave in the GEMM phase
   constexpr int FM = RPW / M::TM;                   // = 2 for both types
   constexpr int FN = NB / M::TM;                    // 2 (f32) / 4 (f64)
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   static_assert((SROWS * VPR) % NTHREADS == 0, "copy-in tiling");
 
   __shared__ __align__(16) T Blk[SROWS * S];   // [diag block (64 rows); chunks] row-major, stride S
-  __shared__ __align__(16) T stage[PBK * LDT];
+  __shared__ __align__(16) T stage[SROWS * LDT];
   __shared__ T rdiag[NB];
   T *Dm = Blk, *Cw = Blk + NB * S;
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
   const int dm0 = (M::TM == 32) ? (wave >> 1) * 32 : wave * 16;
   const int dn0 = (M::TM == 32) ? (wave & 1) * 32 : 0;
-  const bool vcols = vec && (c0 + NB <= n);  // the 64 columns are whole and 16-byte aligned
+  const bool vcols = VECM && (c0 + NB <= n);  // the 64 columns are whole and 16-byte aligned
 
   // ---- copy [D; C] (columns c0..c0+63 of the stacked rows) global -> LDS, 16 bytes per lane ------
   // branch-free (clamped pointer + select) so every load is in flight at once
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
     typename M::acc_t accD[1][DN];
     zero_acc<T, FM, FN>(accC);
     zero_acc<T, 1, DN>(accD);
-    LoaderKC<T, SROWS, PBK> ld;
+    LoaderKC<T, SROWS, PBK, VECM> ld;
     ld.init(
         [&](int s, int64_t &rg) -> const T * {
           const int64_t vrow = (s < NB) ? c0 + s : rbase + (s - NB);
@@ -243,20 +243,16 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
           return vr.ptr(vrow);
         },
         vr.A, tid);
-    ld.load(cJ, cJ, c0, vec, tid);
-    ld.template store<LDT>(stage, tid);
-    __syncthreads();
-    for (int64_t k = cJ; k < c0; k += PBK) {
-      const bool more = k + PBK < c0;
-      if (more) ld.load(k + PBK, cJ, c0, vec, tid);
-      mma_ktile<T, FM, FN, PBK, LDT, LDT>(stage, stage, NB + wave * RPW, 0, lane, accC);
-      mma_ktile<T, 1, DN, PBK, LDT, LDT>(stage, stage, dm0, dn0, lane, accD);
-      __syncthreads();
-      if (more) {
-        ld.template store<LDT>(stage, tid);
-        __syncthreads();
-      }
-    }
+    kloop_kc<PBK>(
+        cJ, c0, ld.fast_end(c0),
+        [&](int64_t k) { ld.load(k, c0, tid); },
+        [&]() { ld.template store<LDT>(stage, tid); },
+        [&](int64_t k) { ld.load_fast(k); },
+        [&]() { ld.template store_fast<LDT>(stage, tid); },
+        [&]() {
+          mma_ktile<T, FM, FN, PBK, true, LDT, true, LDT>(stage, stage, NB + wave * RPW, 0, lane, accC);
+          mma_ktile<T, 1, DN, PBK, true, LDT, true, LDT>(stage, stage, dm0, dn0, lane, accD);
+        });
     STAMP(1);
     // subtract the products from the LDS image; every element belongs to exactly one lane
 #pragma unroll
@@ -359,17 +355,16 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 // above the diagonal exit at once.
 constexpr int SBM = 128;
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_kernel(VRows<T> vr, int64_t strideA,
-                                                              int64_t strideX, int64_t cJ,
-                                                              int64_t kend, int vec) {
+template <typename T, bool VECM>
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_kernel(
+    VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cJ, int64_t kend) {
   using M = Mfma<T>;
   constexpr int SBK = TileK<T>::BK;
   constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
-  constexpr int LD = SBM + KC_PAD;
+  constexpr int LD = SBK + RmPad<T>::V;  // row-major images [128][LD]
   if (blockIdx.x < blockIdx.y) return;
-  __shared__ __align__(16) T As[SBK * LD];
-  __shared__ __align__(16) T Bs[SBK * LD];
+  __shared__ __align__(16) T As[SBM * LD];
+  __shared__ __align__(16) T Bs[SBM * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   vr.A += (int64_t)b * strideA;
@@ -380,14 +375,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
   const bool diag_tile = blockIdx.x == blockIdx.y;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  LoaderKC<T, SBM, SBK> la, lb;
+  LoaderKC<T, SBM, SBK, VECM> la, lb;
   la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return vr.ptr(r0 + s); }, vr.A, tid);
   lb.init([&](int s, int64_t &rg) -> const T * { rg = q0 + s; return (q0 + s < n) ? vr.A + (q0 + s) * vr.lda : nullptr; }, vr.A, tid);
-  la.load(cJ, cJ, kend, vec, tid);
-  lb.load(cJ, cJ, kend, vec, tid);
-
-  // the accumulators start from C (loads in flight together with the first operand tile) and the
-  // A operand is negated on its way into LDS:  acc = C + (-P_r) P_c^T
+  // the accumulators start from -C (its loads are in flight together with the first operand
+  // tile):  acc = -C + P_r P_c^T, stored back negated
   typename M::acc_t acc[F][F];
 #pragma unroll
   for (int fm = 0; fm < F; ++fm)
@@ -397,27 +389,18 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
 #pragma unroll
       for (int fn = 0; fn < F; ++fn) {
         const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
-        acc[fm][fn][r] = (rp != nullptr && c < n) ? rp[c] : vr.A[0];
+        acc[fm][fn][r] = -((rp != nullptr && c < n) ? rp[c] : vr.A[0]);
       }
     }
-
-  la.template store<LD, true>(As, tid);
-  lb.template store<LD>(Bs, tid);
-  __syncthreads();
-  for (int64_t k = cJ; k < kend; k += SBK) {
-    const bool more = k + SBK < kend;
-    if (more) {
-      la.load(k + SBK, cJ, kend, vec, tid);
-      lb.load(k + SBK, cJ, kend, vec, tid);
-    }
-    mma_ktile<T, F, F, SBK, LD, LD>(As, Bs, wm, wn, lane, acc);
-    __syncthreads();
-    if (more) {
-      la.template store<LD, true>(As, tid);
-      lb.template store<LD>(Bs, tid);
-      __syncthreads();
-    }
-  }
+  int64_t kfast = la.fast_end(kend);
+  if (lb.fast_end(kend) < kfast) kfast = lb.fast_end(kend);
+  kloop_kc<SBK>(
+      cJ, kend, kfast,
+      [&](int64_t k) { la.load(k, kend, tid); lb.load(k, kend, tid); },
+      [&]() { la.template store<LD>(As, tid); lb.template store<LD>(Bs, tid); },
+      [&](int64_t k) { la.load_fast(k); lb.load_fast(k); },
+      [&]() { la.template store_fast<LD>(As, tid); lb.template store_fast<LD>(Bs, tid); },
+      [&]() { mma_ktile<T, F, F, SBK, true, LD, true, LD>(As, Bs, wm, wn, lane, acc); });
   // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: nothing to store
   if (diag_tile && wm == 0 && wn == 64) return;
 #pragma unroll
@@ -428,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
 #pragma unroll
       for (int fn = 0; fn < F; ++fn) {
         const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
-        if (rp != nullptr && c < n) rp[c] = acc[fm][fn][r];
+        if (rp != nullptr && c < n) rp[c] = -acc[fm][fn][r];
       }
     }
 }
@@ -455,16 +438,13 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
   }
 }
 
-template <typename T>
-static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+template <typename T, bool VECM>
+static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
                      void *work) {
   constexpr int NCH = PanelCfg<T>::NCH;
   VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
   const int64_t Mv = vr.npad + mx;
-  constexpr int VEC = VecT<T>::N;
-  const int vec = kc_vec_ok<T>(A, lda) && (strideA % VEC == 0) &&
-                  (mx == 0 || (kc_vec_ok<T>(X, ldx) && (strideX % VEC == 0)));
   if (hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     set_error("gpvae_potrf: hipMemsetAsync(info) failed");
     return -12;
@@ -474,13 +454,15 @@ static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda,
     for (int64_t c0 = cJ; c0 < kend; c0 += NB) {
       const int64_t below = Mv - (c0 + NB);
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
-      hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)nwg, (unsigned)batch),
-                         dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, vec, (T *)work, g_stamps);
+      hipLaunchKernelGGL((potrf_panel_kernel<T, VECM>), dim3((unsigned)nwg, (unsigned)batch),
+                         dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work,
+                         g_stamps);
     }
     if (kend < n) {
       const int64_t rt = cdiv(Mv - kend, SBM), ct = cdiv(n - kend, SBM);
-      hipLaunchKernelGGL((potrf_syrk_kernel<T>), dim3((unsigned)rt, (unsigned)ct, (unsigned)batch),
-                         dim3(NTHREADS), 0, st, vr, strideA, strideX, cJ, kend, vec);
+      hipLaunchKernelGGL((potrf_syrk_kernel<T, VECM>),
+                         dim3((unsigned)rt, (unsigned)ct, (unsigned)batch), dim3(NTHREADS), 0, st, vr,
+                         strideA, strideX, cJ, kend);
     }
   }
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
@@ -488,6 +470,20 @@ static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda,
                      0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info, flags);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
+}
+
+// 16-byte loads need every row of A (and X) 16-byte aligned; otherwise the scalar-load build runs
+template <typename T>
+static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                     int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
+                     void *work) {
+  constexpr int VEC = VecT<T>::N;
+  const bool vec = kc_vec_ok<T>(A, lda) && (strideA % VEC == 0) &&
+                   (mx == 0 || (kc_vec_ok<T>(X, ldx) && (strideX % VEC == 0)));
+  return vec ? run_potrf_v<T, true>(st, n, batch, A, lda, strideA, mx, X, ldx, strideX, info, flags,
+                                    work)
+             : run_potrf_v<T, false>(st, n, batch, A, lda, strideA, mx, X, ldx, strideX, info,
+                                     flags, work);
 }
 
 }  // namespace gpvae

@@ -48,14 +48,17 @@ template <typename T> struct GemmArgs {
 
 constexpr int GBM = 128, GBN = 64, GBK = 16;
 
-template <typename T, bool AKC, bool BKC, int EPI>
+// KVEC: the K-contiguous operands (AKC / BKC) are 16-byte aligned row by row
+template <typename T, bool AKC, bool BKC, int EPI, bool KVEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
   constexpr int FM = 32 / M::TM;  // wave tile 32 x 64
   constexpr int FN = 64 / M::TM;
-  constexpr int LDA = GBM + (AKC ? KC_PAD : LdsPad<T>::V), LDB = GBN + (BKC ? KC_PAD : LdsPad<T>::V);
-  __shared__ __align__(16) T As[GBK * LDA];
-  __shared__ __align__(16) T Bs[GBK * LDB];
+  // row-major image [rows][GBK + pad] for a K-contiguous operand, k-major [GBK][rows + pad] otherwise
+  constexpr int LDA = AKC ? GBK + RmPad<T>::V : GBM + LdsPad<T>::V;
+  constexpr int LDB = BKC ? GBK + RmPad<T>::V : GBN + LdsPad<T>::V;
+  __shared__ __align__(16) T As[AKC ? GBM * LDA : GBK * LDA];
+  __shared__ __align__(16) T Bs[BKC ? GBN * LDB : GBK * LDB];
   __shared__ T red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * GBM, n0 = (int64_t)blockIdx.y * GBN;
@@ -63,9 +66,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
   const int64_t Mrows = g.M;  // includes the ones row when present
 
-  LoaderKC<T, GBM, GBK> lak;
+  LoaderKC<T, GBM, GBK, KVEC> lak;
   LoaderMC<T, GBM, GBK, true> lam;
-  LoaderKC<T, GBN, GBK> lbk;
+  LoaderKC<T, GBN, GBK, KVEC> lbk;
   LoaderMC<T, GBN, GBK> lbm;
   if constexpr (AKC)
     lak.init([&](int s, int64_t &rg) -> const T * { rg = m0 + s; return (m0 + s < Mrows) ? g.A + (m0 + s) * g.lda : nullptr; }, g.A, tid);
@@ -74,9 +77,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   const int64_t a_rend = (g.a_ones_row >= 0) ? g.a_ones_row : Mrows;
 
   auto load_tiles = [&](int64_t k0) {
-    if constexpr (AKC) lak.load(k0, kbeg, kend, g.vec_a, tid);
+    if constexpr (AKC) lak.load(k0, kend, tid);
     else lam.load(g.A, g.lda, m0, a_rend, k0, kbeg, kend, g.vec_a, tid, g.a_ones_row);
-    if constexpr (BKC) lbk.load(k0, kbeg, kend, g.vec_b, tid);
+    if constexpr (BKC) lbk.load(k0, kend, tid);
     else lbm.load(g.B, g.ldb, n0, g.N, k0, kbeg, kend, g.vec_b, tid);
   };
   auto store_tiles = [&]() {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
     for (int64_t k = kbeg; k < kend; k += GBK) {
       const bool more = k + GBK < kend;
       if (more) load_tiles(k + GBK);
-      mma_ktile<T, FM, FN, GBK, LDA, LDB>(As, Bs, wave * 32, 0, lane, acc);
+      mma_ktile<T, FM, FN, GBK, AKC, LDA, BKC, LDB>(As, Bs, wave * 32, 0, lane, acc);
       __syncthreads();
       if (more) {
         store_tiles();
@@ -147,7 +150,11 @@ static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
   g.kchunk = kchunk;
   const int64_t nz = g.K > 0 ? cdiv(g.K, kchunk) : 1;
   dim3 grid((unsigned)cdiv(g.M, GBM), (unsigned)cdiv(g.N, GBN), (unsigned)nz);
-  hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI>), grid, dim3(NTHREADS), 0, st, g);
+  const bool kvec = (!AKC || g.vec_a) && (!BKC || g.vec_b);
+  if (kvec || (!AKC && !BKC))
+    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, true>), grid, dim3(NTHREADS), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, false>), grid, dim3(NTHREADS), 0, st, g);
 }
 
 template <typename T> static inline bool mc_vec_ok(const void *base, int64_t ld) {
