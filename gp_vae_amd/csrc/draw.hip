@@ -21,8 +21,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
   constexpr int DBK = TileK<T>::BK;
   constexpr int FR = 64 / M::TM;
   constexpr int LD = DBK + RmPad<T>::V;  // row-major images [128][LD]
-  __shared__ __align__(16) T As[DBM * LD];
-  __shared__ __align__(16) T Bs[DBM * LD];
+  using LA = LoaderKC<T, DBM, DBK, VECM>;
+  using LB = LoaderKC<T, DBM, DBK, VECM, true>;
+  using Pipe = PipeKC<T, FR, FR, DBK, DBM, DBM, LA, LB>;
+  static_assert(Pipe::LD == LD, "image stride");
+  __shared__ __align__(16) T lds[Pipe::LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Plain round-robin placement already puts blocks b, b+8, ... (same column tile of L, row tiles
   // 8 apart) on one XCD; a contiguous-run remap (guide T1) was measured 1.8x SLOWER here because it
@@ -32,8 +35,8 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
   const int64_t r0 = (int64_t)rt * DBM, c0 = (int64_t)ct * DBM;
   const int64_t kend = (c0 + DBM < n) ? c0 + DBM : n;
 
-  LoaderKC<T, DBM, DBK, VECM> la;
-  LoaderKC<T, DBM, DBK, VECM, true> lb;
+  LA la;
+  LB lb;
   la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return (r0 + s < nb) ? E + (r0 + s) * lde : nullptr; }, E, tid);
   lb.init([&](int s, int64_t &rg) -> const T * { rg = c0 + s; return (c0 + s < n) ? L + (c0 + s) * ldl : nullptr; }, L, tid);
 
@@ -41,16 +44,38 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
   zero_acc<T, FR, FR>(acc);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  int64_t kfast = la.fast_end(kend);
-  if (lb.fast_end(kend) < kfast) kfast = lb.fast_end(kend);
-  kloop_kc<DBK>(
-      0, kend, kfast,
-      [&](int64_t k) { la.load(k, kend, tid); lb.load(k, kend, tid); },
-      [&]() { la.template store<LD>(As, tid); lb.template store<LD>(Bs, tid); },
-      [&](int64_t k) { la.load_fast(k); lb.load_fast(k); },
-      [&]() { la.template store_fast<LD>(As, tid); lb.template store_fast<LD>(Bs, tid); },
-      [&]() { mma_ktile<T, FR, FR, DBK, true, LD, true, LD>(As, Bs, wm, wn, lane, acc); });
+  Pipe pipe;
+  pipe.run(la, lb, lds, 0, kend, wm, wn, lane, tid, acc);
   const T sigma = (E2 != nullptr) ? sigma_p[0] : T(0);
+  // whole tile inside the matrices: buffer ops with scalar element offsets, no bounds checks
+  const bool interior = r0 + DBM <= nb && c0 + DBM <= n && TileIO<T>::usable(ldf, 64) &&
+                        TileIO<T>::usable(ldy, 64) && TileIO<T>::usable(lde2, 64);
+  if (interior) {
+    TileIO<T> iof, ioy, ioe;
+    const int64_t rw = r0 + wm, cw = c0 + wn;
+    if (F != nullptr) iof.init(F + rw * ldf + cw, ldf, lane);
+    if (Y != nullptr) ioy.init(Y + rw * ldy + cw, ldy, lane);
+    if (E2 != nullptr) ioe.init(E2 + rw * lde2 + cw, lde2, lane);
+#pragma unroll
+    for (int fm = 0; fm < FR; ++fm) {
+      T e2[FR][M::NACC];
+      if (E2 != nullptr) {
+#pragma unroll
+        for (int fn = 0; fn < FR; ++fn)
+#pragma unroll
+          for (int r = 0; r < M::NACC; ++r) e2[fn][r] = ioe.load(fm, fn, r);
+      }
+#pragma unroll
+      for (int fn = 0; fn < FR; ++fn)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) {
+          const T f = acc[fm][fn][r];
+          if (F != nullptr) iof.store(fm, fn, r, f);
+          if (Y != nullptr) ioy.store(fm, fn, r, (E2 != nullptr) ? f + sigma * e2[fn][r] : f);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int fm = 0; fm < FR; ++fm) {
     T e2[M::NACC][FR];

@@ -65,6 +65,57 @@ __device__ __forceinline__ i32x4_t make_buffer_rsrc(const void *p) {
   return r;
 }
 
+// ---- accumulator-tile access without per-element vector arithmetic ---------------------------------
+// A wave's FM x FN MFMA tiles live at  origin[(fm*TM + row(lane, r)) * ld + fn*TM + col(lane)].
+// row(lane, r) = row(lane, 0) + row(0, r), so the address splits into a per-lane byte offset
+// (one register, loop invariant) and a per-element SCALAR offset: element loads/stores are
+// buffer ops with zero VALU instructions — the epilogue of one block then no longer crawls behind
+// the MFMA stream of the block that shares its SIMDs.  Only for tiles that need no bounds checks
+// and whose 64-row extent stays below 2 GiB (usable()).
+__device__ float raw_buffer_load_f32(i32x4_t rsrc, int voffset, int soffset,
+                                     int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void raw_buffer_store_f32(float v, i32x4_t rsrc, int voffset, int soffset,
+                                     int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+__device__ i32x2_t raw_buffer_load_b64(i32x4_t rsrc, int voffset, int soffset,
+                                       int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+__device__ void raw_buffer_store_b64(i32x2_t v, i32x4_t rsrc, int voffset, int soffset,
+                                     int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+
+template <typename T> struct TileIO {
+  using M = Mfma<T>;
+  i32x4_t rsrc;
+  int voff;
+  int ldb;  // leading dimension in bytes (scalar)
+  __device__ static __forceinline__ bool usable(int64_t ld, int rows) {
+    return (int64_t)rows * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31);
+  }
+  // origin: wave-uniform pointer to the wave's first element
+  __device__ __forceinline__ void init(const T *origin, int64_t ld, int lane) {
+    rsrc = make_buffer_rsrc(origin);
+    ldb = __builtin_amdgcn_readfirstlane((int)(ld * (int64_t)sizeof(T)));
+    voff = M::row(lane, 0) * (int)(ld * (int64_t)sizeof(T)) + M::col(lane) * (int)sizeof(T);
+  }
+  __device__ __forceinline__ int soff(int fm, int fn, int r) const {
+    return (fm * M::TM + M::row(0, r)) * ldb + fn * M::TM * (int)sizeof(T);
+  }
+  __device__ __forceinline__ T load(int fm, int fn, int r) const {
+    if constexpr (sizeof(T) == 4) {
+      return raw_buffer_load_f32(rsrc, voff, soff(fm, fn, r), 0);
+    } else {
+      const i32x2_t t = raw_buffer_load_b64(rsrc, voff, soff(fm, fn, r), 0);
+      return __builtin_bit_cast(double, t);
+    }
+  }
+  __device__ __forceinline__ void store(int fm, int fn, int r, T v) const {
+    if constexpr (sizeof(T) == 4) {
+      raw_buffer_store_f32(v, rsrc, voff, soff(fm, fn, r), 0);
+    } else {
+      raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, v), rsrc, voff, soff(fm, fn, r), 0);
+    }
+  }
+};
+
 // ---- loader: source contiguous along K:  element(r, k) = rowptr[r][k] ------------------------------
 // ROWS x BK tile; per-thread row pointers are fixed over the k loop.  Two paths:
 //   generic  load()/store(): any row set (a row that does not exist reads through `safe` and is
@@ -130,7 +181,9 @@ struct LoaderKC {
     if (TRI && rowg_min + 1 < kend) return rowg_min + 1;  // tiles that stay at or below the diagonal
     return kend;
   }
-  __device__ __forceinline__ void load_fast(int64_t k0) {
+  __device__ __forceinline__ void load_fast(int64_t k0, int64_t kend) {
+    k0_ = k0;  // scalars: a fast-loaded tile may also go through the generic store
+    kend_ = kend;
     const int soff = (int)(k0 * (int64_t)sizeof(T));  // scalar
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
@@ -377,6 +430,149 @@ __device__ __forceinline__ void kloop_kc(int64_t kbeg, int64_t kend, int64_t kfa
     }
   }
 }
+
+// ---- software-pipelined k loop: both operands through LoaderKC, row-major images, LDS double buffer --
+// A wave that alternates "MFMA phase / load-store phase" leaves the MFMA pipe idle during its own
+// load-store phase unless the partner wave happens to be in its MFMA phase — and the SIMD arbiter
+// gives the older wave strict priority, so the two waves do not settle into anti-phase (measured:
+// the older block runs as if alone at ~79 % pipe use, the younger one crawls in its gaps, and the
+// tail of the launch runs single waves).  Here every wave keeps its OWN MFMA stream dense instead:
+// per k-tile t (LDS buffer cur = t & 1, fragment register halves H0 / H1):
+//     a   wait for the global loads of tile t+1 (issued one whole tile ago), ds_write them into
+//         buffer cur^1, issue the global loads of tile t+2
+//     a2  ds_read the second-half fragments of tile t (H1) from buffer cur
+//     b   MFMAs of the first half (H0, read during the previous tile)
+//     c   barrier: every wave has written tile t+1 and finished reading... (see hazards below)
+//     d   ds_read the first-half fragments of tile t+1 (H0) from buffer cur^1
+//     e   MFMAs of the second half (H1)
+// All memory instructions are issued between MFMAs of the same wave and their latencies are a
+// half tile or more ahead of their consumers; the only exposed time is barrier skew.
+// Hazards: buffer cur^1 written in (a) of tile t was last read in (d) of tile t-2 / (a2) of tile
+// t-1, both before the barrier of tile t-1, which the writer has passed.  Reads in (d) of tile t
+// follow the barrier of tile t, after every wave's (a) writes (lgkmcnt(0) before the barrier).
+// Leading tiles whose t+1 and t+2 are plain (LoaderKC::fast_end) run in an unrolled-by-two loop
+// with no VALU instruction besides the MFMAs; the rest takes the generic (masked) loader path.
+template <typename T, int FM, int FN, int BK, int RA, int RB, class LA, class LB>
+struct PipeKC {
+  using M = Mfma<T>;
+  using V = typename VecT<T>::type;
+  static constexpr int LD = BK + RmPad<T>::V;
+  static constexpr int KV = VecT<T>::N;
+  static constexpr int CK = (64 / M::TM) * KV;  // k values per chunk (8)
+  static constexpr int CH = BK / CK;
+  static constexpr int HC = CH / 2;              // chunks per fragment half
+  static constexpr int SZ = (RA + RB) * LD;      // elements per LDS buffer
+  static constexpr int LDS_ELEMS = 2 * SZ;
+  static_assert(CH % 2 == 0, "two fragment halves");
+
+  T ha[2][HC][FM][KV], hb[2][HC][FN][KV];
+
+  template <int BUF, int HALF>
+  __device__ __forceinline__ void read_half(const T *lds, int aoff, int boff) {
+    const T *Ab = lds + BUF * SZ + aoff, *Bb = lds + BUF * SZ + RA * LD + boff;
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const V t = *reinterpret_cast<const V *>(Ab + fm * M::TM * LD + (HALF * HC + c) * CK);
+        const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+        for (int j = 0; j < KV; ++j) ha[HALF][c][fm][j] = tp[j];
+      }
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const V t = *reinterpret_cast<const V *>(Bb + fn * M::TM * LD + (HALF * HC + c) * CK);
+        const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+        for (int j = 0; j < KV; ++j) hb[HALF][c][fn][j] = tp[j];
+      }
+    }
+  }
+  template <int HALF>
+  __device__ __forceinline__ void mma_half(typename M::acc_t (&acc)[FM][FN]) {
+#pragma unroll
+    for (int c = 0; c < HC; ++c)
+#pragma unroll
+      for (int j = 0; j < KV; ++j)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn)
+            acc[fm][fn] = M::mma(ha[HALF][c][fm][j], hb[HALF][c][fn][j], acc[fm][fn]);
+  }
+
+  // one k-tile; CUR compile-time so every LDS offset is an immediate
+  template <int CUR, bool FAST>
+  __device__ __forceinline__ void tile(LA &la, LB &lb, T *lds, int aoff, int boff, int64_t k,
+                                       int64_t kend, int tid, typename M::acc_t (&acc)[FM][FN]) {
+    constexpr int NXT = CUR ^ 1;
+    const bool has1 = FAST || k + BK < kend, has2 = FAST || k + 2 * BK < kend;
+    if (has1) {
+      if constexpr (FAST) {
+        la.template store_fast<LD>(lds + NXT * SZ, tid);
+        lb.template store_fast<LD>(lds + NXT * SZ + RA * LD, tid);
+      } else {
+        la.template store<LD>(lds + NXT * SZ, tid);
+        lb.template store<LD>(lds + NXT * SZ + RA * LD, tid);
+      }
+    }
+    if (has2) {
+      if constexpr (FAST) {
+        la.load_fast(k + 2 * BK, kend);
+        lb.load_fast(k + 2 * BK, kend);
+      } else {
+        la.load(k + 2 * BK, kend, tid);
+        lb.load(k + 2 * BK, kend, tid);
+      }
+    }
+    read_half<CUR, 1>(lds, aoff, boff);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half<0>(acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (has1) read_half<NXT, 0>(lds, aoff, boff);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half<1>(acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // acc += A[am0.., k] B[bn0.., k]^T over k in [kbeg, kend), kbeg < kend; lds holds LDS_ELEMS
+  __device__ __forceinline__ void run(LA &la, LB &lb, T *lds, int64_t kbeg, int64_t kend, int am0,
+                                      int bn0, int lane, int tid,
+                                      typename M::acc_t (&acc)[FM][FN]) {
+    kbeg = uniform64(kbeg);
+    kend = uniform64(kend);
+    int64_t kfast = la.fast_end(kend);
+    if (lb.fast_end(kend) < kfast) kfast = lb.fast_end(kend);
+    kfast = uniform64(kfast);
+    const int lr = lane % M::TM, g = lane / M::TM;
+    const int aoff = (am0 + lr) * LD + g * KV, boff = (bn0 + lr) * LD + g * KV;
+    // leading plain tiles; tile t runs in the fast loop when tiles t+1 and t+2 are plain
+    const int nplain = (kfast > kbeg) ? (int)((kfast - kbeg) / BK) : 0;
+    const int npairs = (nplain >= 4) ? (nplain - 2) / 2 : 0;
+
+    la.load(kbeg, kend, tid);
+    lb.load(kbeg, kend, tid);
+    la.template store<LD>(lds, tid);
+    lb.template store<LD>(lds + RA * LD, tid);
+    if (kbeg + BK < kend) {
+      la.load(kbeg + BK, kend, tid);
+      lb.load(kbeg + BK, kend, tid);
+    }
+    __syncthreads();
+    read_half<0, 0>(lds, aoff, boff);
+    int64_t k = kbeg;
+    for (int i = 0; i < npairs; ++i, k += 2 * BK) {
+      tile<0, true>(la, lb, lds, aoff, boff, k, kend, tid, acc);
+      tile<1, true>(la, lb, lds, aoff, boff, k + BK, kend, tid, acc);
+    }
+    const int nrest = (int)((kend - k + BK - 1) / BK);
+    for (int i = 0; i < nrest; i += 2, k += 2 * BK) {
+      tile<0, false>(la, lb, lds, aoff, boff, k, kend, tid, acc);
+      if (i + 1 < nrest) tile<1, false>(la, lb, lds, aoff, boff, k + BK, kend, tid, acc);
+    }
+  }
+};
 
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void zero_acc(typename Mfma<T>::acc_t (&acc)[FM][FN]) {

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
         cJ, c0, ld.fast_end(c0),
         [&](int64_t k) { ld.load(k, c0, tid); },
         [&]() { ld.template store<LDT>(stage, tid); },
-        [&](int64_t k) { ld.load_fast(k); },
+        [&](int64_t k) { ld.load_fast(k, c0); },
         [&]() { ld.template store_fast<LDT>(stage, tid); },
         [&]() {
           mma_ktile<T, FM, FN, PBK, true, LDT, true, LDT>(stage, stage, NB + wave * RPW, 0, lane, accC);
@@ -363,8 +363,10 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
   constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
   constexpr int LD = SBK + RmPad<T>::V;  // row-major images [128][LD]
   if (blockIdx.x < blockIdx.y) return;
-  __shared__ __align__(16) T As[SBM * LD];
-  __shared__ __align__(16) T Bs[SBM * LD];
+  using LA = LoaderKC<T, SBM, SBK, VECM>;
+  using Pipe = PipeKC<T, F, F, SBK, SBM, SBM, LA, LA>;
+  static_assert(Pipe::LD == LD, "image stride");
+  __shared__ __align__(16) T lds[Pipe::LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   vr.A += (int64_t)b * strideA;
@@ -375,34 +377,55 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
   const bool diag_tile = blockIdx.x == blockIdx.y;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  LoaderKC<T, SBM, SBK, VECM> la, lb;
+  LA la, lb;
   la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return vr.ptr(r0 + s); }, vr.A, tid);
   lb.init([&](int s, int64_t &rg) -> const T * { rg = q0 + s; return (q0 + s < n) ? vr.A + (q0 + s) * vr.lda : nullptr; }, vr.A, tid);
   // the accumulators start from -C (its loads are in flight together with the first operand
-  // tile):  acc = -C + P_r P_c^T, stored back negated
+  // tile):  acc = -C + P_r P_c^T, stored back negated.  A tile whose 128 rows are all rows of A
+  // (no padding rows, no rows of X) and whose columns are all < n goes through TileIO.
   typename M::acc_t acc[F][F];
+  const bool interior = r0 + SBM <= n && q0 + SBM <= n && TileIO<T>::usable(vr.lda, 64);
+  TileIO<T> io;
+  if (interior) {
+    io.init(vr.A + (r0 + wm) * vr.lda + q0 + wn, vr.lda, lane);
+#pragma unroll
+    for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < F; ++fn)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) acc[fm][fn][r] = io.load(fm, fn, r);
+  } else {
+#pragma unroll
+    for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const T *rp = vr.ptr(r0 + wm + fm * M::TM + M::row(lane, r));
+#pragma unroll
+        for (int fn = 0; fn < F; ++fn) {
+          const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
+          acc[fm][fn][r] = (rp != nullptr && c < n) ? rp[c] : vr.A[0];
+        }
+      }
+  }
 #pragma unroll
   for (int fm = 0; fm < F; ++fm)
 #pragma unroll
-    for (int r = 0; r < M::NACC; ++r) {
-      const T *rp = vr.ptr(r0 + wm + fm * M::TM + M::row(lane, r));
+    for (int fn = 0; fn < F; ++fn)
 #pragma unroll
-      for (int fn = 0; fn < F; ++fn) {
-        const int64_t c = q0 + wn + fn * M::TM + M::col(lane);
-        acc[fm][fn][r] = -((rp != nullptr && c < n) ? rp[c] : vr.A[0]);
-      }
-    }
-  int64_t kfast = la.fast_end(kend);
-  if (lb.fast_end(kend) < kfast) kfast = lb.fast_end(kend);
-  kloop_kc<SBK>(
-      cJ, kend, kfast,
-      [&](int64_t k) { la.load(k, kend, tid); lb.load(k, kend, tid); },
-      [&]() { la.template store<LD>(As, tid); lb.template store<LD>(Bs, tid); },
-      [&](int64_t k) { la.load_fast(k); lb.load_fast(k); },
-      [&]() { la.template store_fast<LD>(As, tid); lb.template store_fast<LD>(Bs, tid); },
-      [&]() { mma_ktile<T, F, F, SBK, true, LD, true, LD>(As, Bs, wm, wn, lane, acc); });
+      for (int r = 0; r < M::NACC; ++r) acc[fm][fn][r] = -acc[fm][fn][r];
+  Pipe pipe;
+  pipe.run(la, lb, lds, cJ, kend, wm, wn, lane, tid, acc);
   // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: nothing to store
   if (diag_tile && wm == 0 && wn == 64) return;
+  if (interior) {
+#pragma unroll
+    for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < F; ++fn)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) io.store(fm, fn, r, -acc[fm][fn][r]);
+    return;
+  }
 #pragma unroll
   for (int fm = 0; fm < F; ++fm)
 #pragma unroll
