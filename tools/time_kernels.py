@@ -21,7 +21,7 @@ print(f"draw 4096x4096x4096 f32: {ms:.3f} ms  {n*n*4096/ms/1e9:.1f} TF")
 g = int(np.sqrt(n))
 xs = torch.linspace(0, 1, g, device=dev)
 X = torch.stack(torch.meshgrid(xs, xs, indexing="ij"), -1).reshape(-1, 2).contiguous()
-for batch in (1, 16):
+for batch in (1, 16, 32, 64):
     ls = torch.linspace(0.1, 0.5, batch, device=dev); var = torch.ones(batch, device=dev)
     K = ops.gram_se(X, X, var, ls, jitter=1e-3)
     A = K.clone()
