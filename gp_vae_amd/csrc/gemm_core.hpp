@@ -126,8 +126,9 @@ template <typename T> struct TileIO {
 //       instruction in this phase would wait for the partner wave's whole MFMA phase).  Loads are
 //       buffer_load_dwordx4 with a scalar resource (tile origin), a loop-invariant 32-bit per-lane
 //       byte offset and the k offset in a scalar register; stores are bare ds_write_b128.  Usable
-//       for a k-tile when fast_ok (VECM, every row present and within 2 GiB of the first row) and
-//       the tile needs no masking: k0 + BK <= fast_end(kend).
+//       for a k-tile when fast_ok (every row present and within 2 GiB of the first row; rows need
+//       only 4-byte alignment, buffer loads run in unaligned mode) and the tile needs no masking:
+//       k0 + BK <= fast_end(kend).
 //   VECM (template): all row pointers and k0 are 16-byte aligned (lda % VEC == 0, aligned base);
 //       otherwise VEC scalar loads.  NOTE: in VECM mode the last vector of a row may read up to
 //       round_up(kend, VEC) <= lda: the buffer must span rows * lda elements.
@@ -146,15 +147,23 @@ struct LoaderKC {
   int64_t rowg_min;  // smallest global row of the tile (TRI)
   bool all_ok;       // wave-uniform: every row of the tile exists
   bool fast_ok;      // wave-uniform: the fast path may be used
+  bool kragged;      // wave-uniform: the fast path may take the ragged last k-tile
   int64_t k0_, kend_;
   T regs[NV][VEC];
 
+  // kragged_ext > 0 (elements from the first row of the tile to the end of the array): the fast
+  // path may also take the ragged last k-tile — the caller guarantees that the OTHER operand reads
+  // as zero for k >= kend and that whatever lies behind a row's end is finite (the next row of the
+  // same array); loads past the array return 0 through the buffer range check.
   template <class RowPtr>
-  __device__ __forceinline__ void init(const RowPtr &rowptr, const T *safe, int tid) {
+  __device__ __forceinline__ void init(const RowPtr &rowptr, const T *safe, int tid,
+                                       int64_t kragged_ext = 0) {
+    kragged = kragged_ext > 0 && kragged_ext * (int64_t)sizeof(T) < ((int64_t)1 << 31);
     int64_t rg0;
     const T *base = rowptr(0, rg0);
     rowg_min = rg0;
     rsrc = make_buffer_rsrc(base);
+    if (kragged) rsrc[2] = __builtin_amdgcn_readfirstlane((int)(kragged_ext * (int64_t)sizeof(T)));
     int mine = 1, fits = 1;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
@@ -173,13 +182,13 @@ struct LoaderKC {
     }
     // every thread of the block calls init
     all_ok = __syncthreads_and(mine) != 0;
-    fast_ok = __syncthreads_and(fits) != 0 && all_ok && VECM && EXACT && base != nullptr;
+    fast_ok = __syncthreads_and(fits) != 0 && all_ok && EXACT && base != nullptr;
   }
   // k-tiles [k0, k0+BK) with k0 + BK <= fast_end(kend) may use the fast path
   __device__ __forceinline__ int64_t fast_end(int64_t kend) const {
     if (!fast_ok || kend * (int64_t)sizeof(T) >= ((int64_t)1 << 31)) return INT64_MIN;
     if (TRI && rowg_min + 1 < kend) return rowg_min + 1;  // tiles that stay at or below the diagonal
-    return kend;
+    return kragged ? (kend + BK - 1) / BK * BK : kend;
   }
   __device__ __forceinline__ void load_fast(int64_t k0, int64_t kend) {
     k0_ = k0;  // scalars: a fast-loaded tile may also go through the generic store
@@ -276,6 +285,60 @@ struct LoaderMC {
   static constexpr bool EXACT = (BK * VPK) % NTHREADS == 0;
   using V = typename VecT<T>::type;
   T regs[NV][VEC];
+  i32x4_t rsrc;   // fast path: buffer resource at base + r0
+  int voff[NV];   // fast path: per-lane byte offset of (kk, rc) inside a k-tile
+  int ldb;        // ld in bytes (scalar)
+  bool fast_ok;   // wave-uniform
+
+  // Fast path (no VALU in the k loop, see LoaderKC) for whole k-tiles.  Rows >= rend are NOT
+  // masked: in a product they only feed output rows/columns the caller discards, so whatever the
+  // 16-byte loads find there (the next k-row's data, or 0 past the end of the array — the buffer
+  // resource is sized to the array, out-of-range loads return 0 and never fault) is harmless.
+  // The ones row is patched in store_fast().  Source rows need only 4-byte alignment (buffer
+  // loads in unaligned mode).  nk: number of k-rows of the array.
+  int64_t r0_, ones_row_;
+  bool ones_here;
+  __device__ __forceinline__ void init_fast(const T *base, int64_t ld, int64_t r0, int64_t rend,
+                                            int64_t nk, int tid, int64_t ones_row = -1) {
+    r0_ = r0;
+    ones_row_ = ones_row;
+    ones_here = ONES && ones_row >= r0 && ones_row < r0 + ROWS;
+    const int64_t extent = ((nk - 1) * ld + (rend - r0)) * (int64_t)sizeof(T);  // bytes from base + r0
+    fast_ok = EXACT && rend > r0 && nk > 0 && extent < ((int64_t)1 << 31) &&
+              (nk + BK) * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31);
+    rsrc = make_buffer_rsrc(base + r0);
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)extent);
+    ldb = __builtin_amdgcn_readfirstlane((int)(ld * (int64_t)sizeof(T)));
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int v = tid + p * NTHREADS;
+      voff[p] = (v / VPK) * (int)(ld * (int64_t)sizeof(T)) + (v % VPK) * VEC * (int)sizeof(T);
+    }
+  }
+  __device__ __forceinline__ int64_t fast_end(int64_t kend) const { return fast_ok ? kend : INT64_MIN; }
+  __device__ __forceinline__ void load_fast(int64_t k0) {
+    const int soff = (int)k0 * ldb;  // scalar
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const i32x4_t t = raw_buffer_load_b128(rsrc, voff[p], soff, 0);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) regs[p][e] = tp[e];
+    }
+  }
+  template <int LD> __device__ __forceinline__ void store_fast(T *lds, int tid) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int v = tid + p * NTHREADS;
+      const int kk = v / VPK, rc = (v % VPK) * VEC;
+      V t;
+      T *tp = reinterpret_cast<T *>(&t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        tp[e] = (ONES && ones_here && r0_ + rc + e == ones_row_) ? T(1) : regs[p][e];
+      *reinterpret_cast<V *>(lds + kk * LD + rc) = t;
+    }
+  }
 
   // rows [r0, r0+ROWS) clipped to < rend; k in [k0, k0+BK) clipped to [kbeg, kend).
   // vec (uniform): base and ld are 16-byte aligned, so a whole in-range vector can be one load.

@@ -37,21 +37,25 @@ template <typename T> struct GemmArgs {
   int64_t ldc;
   int64_t M, N, K;
   int64_t kchunk;       // k range per blockIdx.z
-  int64_t a_ones_row;   // AKC == false: A row index that reads as ones (-1: none)
+  int64_t a_ones_row = -1;  // AKC == false: A row index that reads as ones (-1: none)
+  int64_t b_ones_row = -1;  // BKC == false: B column index that reads as ones (-1: none)
   const T *bias;        // EPI_BIAS / EPI_DF: per column
   const T *Yref;        // EPI_DF: data, ld = ldy
   int64_t ldy;
   T inv_var;            // EPI_DF: 1/obs_sigma^2
   T *loss;              // EPI_DF: += 0.5 * sum diff^2 * inv_var
   int vec_a, vec_b;
+  int trans_c;          // store C transposed: C[col * ldc + row] (EPI_STORE / EPI_ATOMIC)
 };
 
-constexpr int GBM = 128, GBN = 64, GBK = 16;
+constexpr int GBM = 128, GBN = 64;
+template <typename T> struct GemmK { static constexpr int BK = TileK<T>::BK; };
 
 // KVEC: the K-contiguous operands (AKC / BKC) are 16-byte aligned row by row
 template <typename T, bool AKC, bool BKC, int EPI, bool KVEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
+  constexpr int GBK = GemmK<T>::BK;
   constexpr int FM = 32 / M::TM;  // wave tile 32 x 64
   constexpr int FN = 64 / M::TM;
   // row-major image [rows][GBK + pad] for a K-contiguous operand, k-major [GBK][rows + pad] otherwise
@@ -65,46 +69,66 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
   const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
   const int64_t Mrows = g.M;  // includes the ones row when present
+  const int64_t a_rend = (g.a_ones_row >= 0) ? g.a_ones_row : Mrows;
 
   LoaderKC<T, GBM, GBK, KVEC> lak;
   LoaderMC<T, GBM, GBK, true> lam;
   LoaderKC<T, GBN, GBK, KVEC> lbk;
-  LoaderMC<T, GBN, GBK> lbm;
-  if constexpr (AKC)
-    lak.init([&](int s, int64_t &rg) -> const T * { rg = m0 + s; return (m0 + s < Mrows) ? g.A + (m0 + s) * g.lda : nullptr; }, g.A, tid);
-  if constexpr (BKC)
+  LoaderMC<T, GBN, GBK, true> lbm;
+  const int64_t b_rend = (g.b_ones_row >= 0) ? g.b_ones_row : g.N;
+  int64_t kfast = INT64_MAX;
+  if constexpr (!AKC) {
+    lam.init_fast(g.A, g.lda, m0, a_rend, g.K, tid, g.a_ones_row);
+    if (lam.fast_end(kend) < kfast) kfast = lam.fast_end(kend);
+  }
+  if constexpr (!BKC) {
+    lbm.init_fast(g.B, g.ldb, n0, b_rend, g.K, tid, g.b_ones_row);
+    if (lbm.fast_end(kend) < kfast) kfast = lbm.fast_end(kend);
+  }
+  if constexpr (AKC) {
+    // ragged last k-tile on the fast path: B (k-rows past K read as zero through its buffer range
+    // check) supplies the zeros, A's rows are contiguous in one array (finite values behind a row)
+    const bool kr = !BKC && lbm.fast_ok && kend == g.K && g.lda == g.K;
+    lak.init([&](int s, int64_t &rg) -> const T * { rg = m0 + s; return (m0 + s < Mrows) ? g.A + (m0 + s) * g.lda : nullptr; }, g.A, tid,
+             kr ? (Mrows - m0) * g.lda : 0);
+    if (lak.fast_end(kend) < kfast) kfast = lak.fast_end(kend);
+  }
+  if constexpr (BKC) {
     lbk.init([&](int s, int64_t &rg) -> const T * { rg = n0 + s; return (n0 + s < g.N) ? g.B + (n0 + s) * g.ldb : nullptr; }, g.B, tid);
-  const int64_t a_rend = (g.a_ones_row >= 0) ? g.a_ones_row : Mrows;
-
-  auto load_tiles = [&](int64_t k0) {
-    if constexpr (AKC) lak.load(k0, kend, tid);
-    else lam.load(g.A, g.lda, m0, a_rend, k0, kbeg, kend, g.vec_a, tid, g.a_ones_row);
-    if constexpr (BKC) lbk.load(k0, kend, tid);
-    else lbm.load(g.B, g.ldb, n0, g.N, k0, kbeg, kend, g.vec_b, tid);
-  };
-  auto store_tiles = [&]() {
-    if constexpr (AKC) lak.template store<LDA>(As, tid);
-    else lam.template store<LDA>(As, tid);
-    if constexpr (BKC) lbk.template store<LDB>(Bs, tid);
-    else lbm.template store<LDB>(Bs, tid);
-  };
+    if (lbk.fast_end(kend) < kfast) kfast = lbk.fast_end(kend);
+  }
+  if (kfast > kend + GBK) kfast = kend;
 
   typename M::acc_t acc[FM][FN];
   zero_acc<T, FM, FN>(acc);
   if (kbeg < kend) {
-    load_tiles(kbeg);
-    store_tiles();
-    __syncthreads();
-    for (int64_t k = kbeg; k < kend; k += GBK) {
-      const bool more = k + GBK < kend;
-      if (more) load_tiles(k + GBK);
-      mma_ktile<T, FM, FN, GBK, AKC, LDA, BKC, LDB>(As, Bs, wave * 32, 0, lane, acc);
-      __syncthreads();
-      if (more) {
-        store_tiles();
-        __syncthreads();
-      }
-    }
+    kloop_kc<GBK>(
+        kbeg, kend, kfast,
+        [&](int64_t k0) {
+          if constexpr (AKC) lak.load(k0, kend, tid);
+          else lam.load(g.A, g.lda, m0, a_rend, k0, kbeg, kend, g.vec_a, tid, g.a_ones_row);
+          if constexpr (BKC) lbk.load(k0, kend, tid);
+          else lbm.load(g.B, g.ldb, n0, b_rend, k0, kbeg, kend, g.vec_b, tid, g.b_ones_row);
+        },
+        [&]() {
+          if constexpr (AKC) lak.template store<LDA>(As, tid);
+          else lam.template store<LDA>(As, tid);
+          if constexpr (BKC) lbk.template store<LDB>(Bs, tid);
+          else lbm.template store<LDB>(Bs, tid);
+        },
+        [&](int64_t k0) {
+          if constexpr (AKC) lak.load_fast(k0, kend);
+          else lam.load_fast(k0);
+          if constexpr (BKC) lbk.load_fast(k0, kend);
+          else lbm.load_fast(k0);
+        },
+        [&]() {
+          if constexpr (AKC) lak.template store_fast<LDA>(As, tid);
+          else lam.template store_fast<LDA>(As, tid);
+          if constexpr (BKC) lbk.template store_fast<LDB>(Bs, tid);
+          else lbm.template store_fast<LDB>(Bs, tid);
+        },
+        [&]() { mma_ktile<T, FM, FN, GBK, AKC, LDA, BKC, LDB>(As, Bs, wave * 32, 0, lane, acc); });
   }
 
   T lsum = T(0);
@@ -118,10 +142,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
         const int64_t col = n0 + fn * M::TM + M::col(lane);
         const bool in = row < Mrows && col < g.N;
         const T v = acc[fm][fn][r];
+        const int64_t ci = g.trans_c ? col * g.ldc + row : row * g.ldc + col;
         if constexpr (EPI == EPI_STORE) {
-          if (in) g.C[row * g.ldc + col] = v;
+          if (in) g.C[ci] = v;
         } else if constexpr (EPI == EPI_ATOMIC) {
-          if (in) atomicAdd(&g.C[row * g.ldc + col], v);
+          if (in) atomicAdd(&g.C[ci], v);
         } else if constexpr (EPI == EPI_BIAS) {
           if (in) g.C[row * g.ldc + col] = v + g.bias[col];
         } else {
@@ -145,6 +170,7 @@ template <typename T, bool AKC, bool BKC, int EPI>
 static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
   if (g.M <= 0 || g.N <= 0) return;
   if (splitk < 1) splitk = 1;
+  constexpr int GBK = GemmK<T>::BK;
   int64_t kchunk = round_up(cdiv(g.K, splitk), GBK);
   if (kchunk < GBK) kchunk = GBK;
   g.kchunk = kchunk;
@@ -478,7 +504,7 @@ __global__ void adam_kernel(int64_t count, T *p, const T *g, T *m, T *v, T lr, T
 static inline int pick_splitk(int64_t tiles, int64_t K) {
   int s = (int)(1024 / (tiles > 0 ? tiles : 1));
   if (s < 1) s = 1;
-  const int64_t maxs = cdiv(K, 4 * GBK);  // at least 4 k-tiles per slice
+  const int64_t maxs = cdiv(K, 4 * 32);  // at least 4 (f32) k-tiles per slice
   if (s > maxs) s = (int)(maxs > 0 ? maxs : 1);
   return s;
 }
