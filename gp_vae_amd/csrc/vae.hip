@@ -132,6 +132,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   }
 
   T lsum = T(0);
+  // whole tile inside C: element addresses split into a per-lane and a scalar part (TileIO)
+  const bool interior = EPI != EPI_ATOMIC && !g.trans_c && m0 + GBM <= Mrows && n0 + GBN <= g.N &&
+                        TileIO<T>::usable(g.ldc, 32) && (EPI != EPI_DF || TileIO<T>::usable(g.ldy, 32));
+  if (interior) {
+    TileIO<T> ioc, ioy;
+    const int64_t rw = m0 + wave * 32;
+    ioc.init(g.C + rw * g.ldc + n0, g.ldc, lane);
+    if constexpr (EPI == EPI_DF) ioy.init(g.Yref + rw * g.ldy + n0, g.ldy, lane);
+    T bias[FN];
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_DF) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) bias[fn] = g.bias[n0 + fn * M::TM + M::col(lane)];
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      T y[FN][M::NACC];
+      if constexpr (EPI == EPI_DF) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int r = 0; r < M::NACC; ++r) y[fn][r] = ioy.load(fm, fn, r);
+      }
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) {
+          const T v = acc[fm][fn][r];
+          if constexpr (EPI == EPI_STORE) {
+            ioc.store(fm, fn, r, v);
+          } else if constexpr (EPI == EPI_BIAS) {
+            ioc.store(fm, fn, r, v + bias[fn]);
+          } else if constexpr (EPI == EPI_DF) {
+            const T diff = v + bias[fn] - y[fn][r];
+            lsum += diff * diff;
+            ioc.store(fm, fn, r, diff * g.inv_var);
+          }
+        }
+    }
+  } else {
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
@@ -158,6 +197,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
         }
       }
     }
+  }
   if constexpr (EPI == EPI_DF) {
     lsum = wave_sum<T>(lsum);
     if (lane == 0) red[wave] = lsum;
