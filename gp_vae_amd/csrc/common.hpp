@@ -85,4 +85,24 @@ template <> struct Mfma<double> {
   __device__ static __forceinline__ int col(int lane) { return lane & 15; }
 };
 
+// 16x16x4 tiles for the small blocked updates inside the Cholesky panel (both types): lane l
+// supplies A[l % 16][l / 16] and B[l / 16][l % 16]; accumulator register r of lane l holds
+// C[row(l, r)][l % 16].
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<float> {
+  using acc_t = f32x4v;
+  __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+template <> struct Mfma16<double> {
+  using acc_t = f64x4;
+  __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
 }  // namespace gpvae

@@ -24,13 +24,13 @@ namespace gpvae {
 constexpr int NB = 64;     // inner (panel) block
 constexpr int NBO = 256;   // outer block
 
-// developer probe: when set (gpvae_dev_set_stamps), block (0,0) of every panel launch writes
-// s_memtime at its phase boundaries to stamps[0..7]
+// developer probe: when set (gpvae_dev_set_stamps), block (0,0) of the panel launch of column
+// block c0/64 writes s_memtime at its phase boundaries to stamps[8*(c0/64) + 0..7]
 static unsigned long long *g_stamps = nullptr;
 #define STAMP(i)                                                                   \
   do {                                                                             \
     if (stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)       \
-      stamps[i] = __builtin_amdgcn_s_memtime();                                    \
+      stamps[8 * (c0 / NB) + i] = __builtin_amdgcn_s_memtime();                                    \
   } while (0)
 
 template <typename T> struct VRows {
@@ -84,27 +84,32 @@ template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
   return r;
 }
 
-// lane = row sweep.  x[0..63]: the lane's row of the block (in: right-hand side, out: solution).
-// Lrow: LDS [64][S] rows of L11;  rdiag: LDS [64] reciprocals of diag(L11).
-// DIAG = true factors the block itself (x is the row of the symmetric block; L11 and rdiag are
-// produced);  DIAG = false solves x L11^T = c for a row below the block.
-// zoff is a per-lane zero the compiler cannot see through: it keeps the broadcast LDS reads of a
-// row of L in VGPRs (a provably uniform address makes hipcc add a v_readlane per value).
-// Returns (DIAG only) the first column whose pivot was not > 0, or -1.
+// ---- blocked (16-column windows) lane = row sweeps ---------------------------------------------------
+// A 64-step sweep costs 2016 dependent FMAs per lane.  Split into four 16-column windows it costs
+// 4 x 120, and the contribution of a finished window to the columns right of it is applied with
+// 16x16x4 MFMAs on the LDS images (at most 16 per step, independent accumulators).  W is the first
+// column of the window (run-time: the windows share one copy of the code), x[16] the lane's entries.
+//
+// DIAG (factor): row c+1 of L inside the window is fetched from LDS (broadcast read) while step c
+// computes; only its newest entry travels by v_readlane (a readlane per entry was measured 45 %
+// slower than the LDS broadcast).
+// Solve: row c of L11 is the same for every lane and is read from LDS as a broadcast (zoff: a
+// per-lane zero the compiler cannot see through keeps those reads in VGPRs, a provably uniform
+// address makes hipcc add a v_readlane per value).
 template <typename T, int S, bool DIAG>
-__device__ __forceinline__ int tri_rows(T (&x)[NB], T *Lrow, T *rdiag, int lane, int zoff) {
+__device__ __forceinline__ int sweep16(T (&x)[16], T *Lrow, T *rdiag, int W, int lane, int zoff,
+                                       int fail) {
   constexpr int VEC = VecT<T>::N;
   using V = typename VecT<T>::type;
-  int fail = -1;
   if constexpr (DIAG) {
-    T cur[NB], nxt[NB];
+    T cur[16], nxt[16];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      // rows of L are final up to column j-1: fetch row j+1's known part while step j computes
-      if (j + 1 < NB) {
+    for (int j = 0; j < 16; ++j) {
+      const int c = W + j;
+      if (j + 1 < 16) {
 #pragma unroll
         for (int k = 0; k < j; k += VEC) {
-          const V t = *reinterpret_cast<const V *>(&Lrow[(j + 1) * S + k + zoff]);
+          const V t = *reinterpret_cast<const V *>(&Lrow[(c + 1) * S + W + k + zoff]);
           const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) nxt[k + e] = tp[e];
@@ -114,36 +119,139 @@ __device__ __forceinline__ int tri_rows(T (&x)[NB], T *Lrow, T *rdiag, int lane,
 #pragma unroll
       for (int k = 0; k < j; ++k) acc[k & 3] -= x[k] * cur[k];
       const T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      const T piv = lane_bcast<T>(s, j);
-      if (!(piv > T(0)) && fail < 0) fail = j;
+      const T piv = lane_bcast<T>(s, c);
+      if (!(piv > T(0)) && fail < 0) fail = c;
       const T rd = fast_rsqrt<T>(piv);
-      T v = (lane > j) ? s * rd : T(0);
-      if (lane == j) v = piv * rd;
+      T v = (lane > c) ? s * rd : T(0);
+      if (lane == c) v = piv * rd;
       x[j] = v;
-      Lrow[lane * S + j] = v;
-      if (lane == 0) rdiag[j] = rd;
-      if (j + 1 < NB) {
-        nxt[j] = lane_bcast<T>(v, j + 1);
+      Lrow[lane * S + c] = v;
+      if (lane == 0) rdiag[c] = rd;
+      if (j + 1 < 16) {
+        nxt[j] = lane_bcast<T>(v, c + 1);
 #pragma unroll
         for (int k = 0; k <= j; ++k) cur[k] = nxt[k];
       }
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < 16; ++j) {
+      const int c = W + j;
       T acc[4] = {x[j], T(0), T(0), T(0)};
 #pragma unroll
       for (int k = 0; k < j; k += VEC) {
-        const V t = *reinterpret_cast<const V *>(&Lrow[j * S + k + zoff]);
+        const V t = *reinterpret_cast<const V *>(&Lrow[c * S + W + k + zoff]);
         const T *tp = reinterpret_cast<const T *>(&t);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
           if (k + e < j) acc[(k + e) & 3] -= x[k + e] * tp[e];
       }
-      x[j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[j + zoff];
+      x[j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[c + zoff];
     }
   }
   return fail;
+}
+
+// Columns right of a finished window:  C[I, J] -= A[I, window] * L[J, window]^T  for the 16-row
+// tiles I = 0..3 of the 64 rows in Cimg and the column blocks J > W/16 (DIAG: Cimg = Limg = the
+// block being factored, lower tiles I >= J only).  Row-major LDS images, stride S, one wave.
+// k values are dealt to the four lane groups in runs of VEC (one 16-byte read per operand and
+// chunk), the same way for both operands.
+template <typename T, int S, bool DIAG>
+__device__ __forceinline__ void upd_window(T *Cimg, const T *Limg, int W, int lane) {
+  using M = Mfma16<T>;
+  using V = typename VecT<T>::type;
+  constexpr int KV = VecT<T>::N, CK = 4 * KV, CH = 16 / CK;
+  const int lr = lane & 15, g = lane >> 4;
+  T a[4][CH][KV];
+#pragma unroll
+  for (int I = 0; I < 4; ++I)
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const V t = *reinterpret_cast<const V *>(&Cimg[(I * 16 + lr) * S + W + ch * CK + g * KV]);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < KV; ++e) a[I][ch][e] = -tp[e];
+    }
+#pragma unroll
+  for (int J = W / 16 + 1; J < 4; ++J) {
+    T bq[CH][KV];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const V t = *reinterpret_cast<const V *>(&Limg[(J * 16 + lr) * S + W + ch * CK + g * KV]);
+      const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+      for (int e = 0; e < KV; ++e) bq[ch][e] = tp[e];
+    }
+    typename M::acc_t c[4];
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+      if (!DIAG || I >= J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[I][r] = Cimg[(I * 16 + M::row(lane, r)) * S + J * 16 + lr];
+      }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+      for (int e = 0; e < KV; ++e)
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+          if (!DIAG || I >= J) c[I] = M::mma(a[I][ch][e], bq[ch][e], c[I]);
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+      if (!DIAG || I >= J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cimg[(I * 16 + M::row(lane, r)) * S + J * 16 + lr] = c[I][r];
+      }
+  }
+}
+
+// one window of a 64-row image: load the lane's 16 entries, sweep, store, update to the right
+template <typename T, int S, bool DIAG>
+__device__ __forceinline__ int window16(T *img, T *Dm, T *rdiag, int W, int lane, int zoff, int fail) {
+  constexpr int VEC = VecT<T>::N;
+  using V = typename VecT<T>::type;
+  T x[16];
+  T *row = &img[lane * S + W];
+#pragma unroll
+  for (int k = 0; k < 16; k += VEC) {
+    const V t = *reinterpret_cast<const V *>(&row[k]);
+    const T *tp = reinterpret_cast<const T *>(&t);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) x[k + e] = tp[e];
+  }
+  fail = sweep16<T, S, DIAG>(x, Dm, rdiag, W, lane, zoff, fail);
+#pragma unroll
+  for (int k = 0; k < 16; k += VEC) {
+    V t;
+    T *tp = reinterpret_cast<T *>(&t);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tp[e] = x[k + e];
+    *reinterpret_cast<V *>(&row[k]) = t;
+  }
+  if (W + 16 < NB) upd_window<T, S, DIAG>(img, Dm, W, lane);
+  return fail;
+}
+
+// factor the 64x64 block in Dm (one wave, lane = row); returns the first bad pivot column or -1
+template <typename T, int S>
+__device__ __forceinline__ int diag_block16(T *Dm, T *rdiag, int lane, int zoff) {
+  int fail = -1;
+#pragma unroll
+  for (int W = 0; W < NB; W += 16) fail = window16<T, S, true>(Dm, Dm, rdiag, W, lane, zoff, fail);
+  return fail;
+}
+
+// solve X L11^T = C for the 64 rows in Cw (one wave, lane = row), in place
+template <typename T, int S>
+__device__ __forceinline__ void trsm_block16(T *Cw, T *Dm, T *rdiag, int lane, int zoff) {
+  if constexpr (sizeof(T) == 4) {  // measured: f32 is faster unrolled, f64 as a run-time loop
+#pragma unroll
+    for (int W = 0; W < NB; W += 16) window16<T, S, false>(Cw, Dm, rdiag, W, lane, zoff, -1);
+  } else {
+#pragma unroll 1
+    for (int W = 0; W < NB; W += 16) window16<T, S, false>(Cw, Dm, rdiag, W, lane, zoff, -1);
+  }
 }
 
 template <typename T, bool VECM>
@@ -276,15 +384,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 
   // ---- (b) factor the diagonal block: wave 0, lane = row ----------------------------------------
   if (wave == 0) {
-    T x[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k += VEC) {
-      const V t = *reinterpret_cast<const V *>(&Dm[lane * S + k]);
-      const T *tp = reinterpret_cast<const T *>(&t);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) x[k + e] = tp[e];
-    }
-    const int fail = tri_rows<T, S, true>(x, Dm, rdiag, lane, zoff);
+    const int fail = diag_block16<T, S>(Dm, rdiag, lane, zoff);
     if (blockIdx.x == 0 && lane == 0 && fail >= 0 && c0 + fail < n) {
       if (info[b] == 0) info[b] = (int32_t)(c0 + fail + 1);
     }
@@ -293,26 +393,8 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   STAMP(3);
 
   // ---- (c) solve the chunks: one chunk per wave, lane = row -----------------------------------
-  if (wave < NCH && rbase + wave * NB < Mv) {
-    T x[NB];
-    T *row = &Cw[(wave * NB + lane) * S];
-#pragma unroll
-    for (int k = 0; k < NB; k += VEC) {
-      const V t = *reinterpret_cast<const V *>(&row[k]);
-      const T *tp = reinterpret_cast<const T *>(&t);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) x[k + e] = tp[e];
-    }
-    tri_rows<T, S, false>(x, Dm, rdiag, lane, zoff);
-#pragma unroll
-    for (int k = 0; k < NB; k += VEC) {
-      V t;
-      T *tp = reinterpret_cast<T *>(&t);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) tp[e] = x[k + e];
-      *reinterpret_cast<V *>(&row[k]) = t;
-    }
-  }
+  if (wave < NCH && rbase + wave * NB < Mv)
+    trsm_block16<T, S>(&Cw[wave * NB * S], Dm, rdiag, lane, zoff);
   __syncthreads();
   STAMP(4);
 
