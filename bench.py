@@ -82,6 +82,18 @@ def cpu_baseline(steps=3):
                       "normals pre-generated, %.1f s" % (done, t_used)}
 
 
+def pmc_traffic():
+    """HBM bytes per draw launch from the committed PMC passes (profiles/r01_draw_pmc.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/prof_draw.py at this shape, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_draw_pmc.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"]), "profiles/r01_draw_pmc.json"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def potrf_microbench(ops, x, batch=16, iters=3):
     """Batched Cholesky TFLOP/s: `batch` Gram matrices with ls on a ladder."""
     dev = x.device
@@ -112,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--group", type=int, default=8, help="steps whose factors are built as one batch")
+    ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +165,18 @@ def main():
     eng.draw_events = None
     loss_last = float(eng.loss.item())
 
+    # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
+    chol = [potrf_microbench(ops, x, batch=b) for b in (16, 64)]
+    if world > 1:
+        for c in chol:
+            tt = torch.tensor([c["tflops"], float(c["all_pd"])], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            c["tflops"] = float(tt[0].item())
+            c["all_pd"] = bool(tt[1].item() == world)
+    for c in chol:
+        c["frac_of_f32_mfma_peak"] = c["tflops"] / (PEAK_F32_MFMA_TFLOPS * world)
+        c["n_gpus"] = world
+
     if rank == 0:
         flop = float(N) * N * B  # algorithmic: n^2 * B  (draw TRMM)
         achieved = flop / (draw_ms * 1e-3) / 1e12 if draw_ms else None
@@ -181,8 +205,10 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
                          "traffic": None, "avg_launch_ms": draw_ms, "flop_per_launch": flop},
             "final_loss": loss_last,
+            "cholesky": chol[0],
+            "cholesky_batch64": chol[1],
         }
-        out["cholesky"] = potrf_microbench(ops, x)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
