@@ -8,7 +8,11 @@
  *
  * Conventions (all entry points):
  *   - plain C, no torch / no C++ types; every pointer except `stream` is a DEVICE pointer owned by
- *     the caller; matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *     the caller; matrices are row-major with an explicit leading dimension in ELEMENTS; a matrix
+ *     with `rows` rows and leading dimension `ld` must be backed by rows*ld readable elements (the
+ *     16-byte loads of the last row may touch its padding), and a dense `ld == cols` matrix may be
+ *     read up to one 16-byte vector past a row's end INTO THE NEXT ROW of the same array — never past
+ *     the array (loads past it are suppressed by the buffer range check);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous and
  *     stream-ordered, never synchronise the device and never allocate device memory
  *     (workspaces are caller-provided; sizes come from the *_workspace_bytes queries);
