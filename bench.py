@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_F64_MFMA_TFLOPS = 78.6   # dense f64 matrix peak
 GRID = 64
 N = GRID * GRID
 B = 4096
@@ -94,12 +95,14 @@ def pmc_traffic():
         return None, None
 
 
-def potrf_microbench(ops, x, batch=16, iters=3):
-    """Batched Cholesky TFLOP/s: `batch` Gram matrices with ls on a ladder."""
+def potrf_microbench(ops, x, batch=32, iters=3, dtype=torch.float32):
+    """Batched Cholesky TFLOP/s: `batch` Gram matrices with ls on the ladder linspace(0.05, 1, batch),
+    var = 1 (batch 32)."""
     dev = x.device
-    ls = torch.linspace(0.05, 1.0, batch, device=dev)
-    var = torch.ones(batch, device=dev)
-    Kb = torch.empty((batch, N, N), device=dev)
+    x = x.to(dtype)
+    ls = torch.linspace(0.05, 1.0, batch, device=dev, dtype=dtype)
+    var = torch.ones(batch, device=dev, dtype=dtype)
+    Kb = torch.empty((batch, N, N), device=dev, dtype=dtype)
     info = None
     times = []
     for it in range(iters + 1):
@@ -112,9 +115,8 @@ def potrf_microbench(ops, x, batch=16, iters=3):
         if it > 0:
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
-    return {"batch": batch, "n": N, "ms": t * 1e3, "tflops": batch * N ** 3 / 3 / t / 1e12,
-            "frac_of_f32_mfma_peak": batch * N ** 3 / 3 / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "all_pd": bool((info == 0).all().item())}
+    return {"batch": batch, "n": N, "dtype": "f32" if dtype == torch.float32 else "f64", "ms": t * 1e3,
+            "tflops": batch * N ** 3 / 3 / t / 1e12, "all_pd": bool((info == 0).all().item())}
 
 
 def main():
@@ -166,7 +168,8 @@ def main():
     loss_last = float(eng.loss.item())
 
     # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
-    chol = [potrf_microbench(ops, x, batch=b) for b in (16, 64)]
+    chol = [potrf_microbench(ops, x, batch=32), potrf_microbench(ops, x, batch=args.group),
+            potrf_microbench(ops, x, batch=16, dtype=torch.float64)]
     if world > 1:
         for c in chol:
             tt = torch.tensor([c["tflops"], float(c["all_pd"])], dtype=torch.float64, device=dev)
@@ -174,7 +177,8 @@ def main():
             c["tflops"] = float(tt[0].item())
             c["all_pd"] = bool(tt[1].item() == world)
     for c in chol:
-        c["frac_of_f32_mfma_peak"] = c["tflops"] / (PEAK_F32_MFMA_TFLOPS * world)
+        peak = PEAK_F32_MFMA_TFLOPS if c["dtype"] == "f32" else PEAK_F64_MFMA_TFLOPS
+        c["frac_of_mfma_peak"] = c["tflops"] / (peak * world)
         c["n_gpus"] = world
 
     if rank == 0:
@@ -206,7 +210,8 @@ def main():
                          "traffic": None, "avg_launch_ms": draw_ms, "flop_per_launch": flop},
             "final_loss": loss_last,
             "cholesky": chol[0],
-            "cholesky_batch64": chol[1],
+            "cholesky_factor_group": chol[1],
+            "cholesky_f64": chol[2],
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:

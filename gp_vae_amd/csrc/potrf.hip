@@ -325,6 +325,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
           if ((vrow >= n || c0 + j + e >= n)) tmp[p][e] = (s == j + e) ? T(1) : T(0);
       }
     }
+    STAMP(6);
 #pragma unroll
     for (int p = 0; p < NVC; ++p) {
       const int v = tid + p * NTHREADS;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
       for (int e = 0; e < VEC; ++e) tp[e] = tmp[p][e];
       *reinterpret_cast<V *>(&Blk[s * S + j]) = t;
     }
+    STAMP(7);
   }
 
   // ---- (a) apply columns [cJ, c0) of the outer block: [D; C] -= [Pd; Pc] Pd^T ------------------

@@ -1,0 +1,115 @@
+"""Measurements at the BASELINE.json configs that are not the bench line.
+One JSON object per config on stdout; results are quoted in DESIGN.md §5 and kept in
+profiles/r01_configs.json.   usage: python tools/bench_configs.py [c2] [c4] [c5]"""
+import sys, os, json, math, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gp_vae_amd import ops
+from gp_vae_amd.gp import exp_kernel2
+from gp_vae_amd.vae import StepEngine, SVIState, init_params, decoder_list_from_flat
+from gp_vae_amd.inference import GPInference, VAEInference
+
+dev = torch.device("cuda", 0)
+which = set(a.lower() for a in sys.argv[1:]) or {"c2", "c4", "c5"}
+
+
+def timed(f, reps):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+if "c2" in which:  # 1D grid n=1024, B=4096, reference MLP (35,30,10), fp32, jitter 1e-4
+    n, B, dims = 1024, 4096, (35, 30, 10)
+    x = torch.arange(n, dtype=torch.float32, device=dev) / n
+    def hyper(rng):  # vae.py:157-159 priors, ls clipped as in bench.py (heavy InverseGamma tail)
+        from gp_vae_amd.gp import draw_hyper
+        ls, var, sig = draw_hyper(rng)
+        return min(max(ls, 0.05), 1.0), var, sig
+    eng = StepEngine(x, 1e-4, dims, B, 1e-3, dtype=torch.float32, seed=1, hyper_sampler=hyper, group=16)
+    st = SVIState(init_params(n, *dims, 1, torch.float32, dev))
+    eng.run([(0, i) for i in range(16)], st, train=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = 128
+    eng.run([(1, i) for i in range(steps)], st, train=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"config": "C2: 1D n=1024, B=4096, VAE 1024-35-30-10, f32", "draws_per_s": B * steps / dt,
+                      "ms_per_step": dt / steps * 1e3, "final_loss": float(eng.loss.item())}), flush=True)
+
+if "c4" in which:  # kriging, 192x192 grid, 32768 observations, fp64
+    g = np.arange(192) / 192.0
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1)
+    rng = np.random.default_rng(0)
+    obs = np.sort(rng.permutation(x.shape[0])[:32768])
+    y = np.sin(3 * np.pi * x[:, 0]) + 0.3 * np.cos(9 * np.pi * x[:, 1]) + 0.5 * np.sin(7 * np.pi * (x[:, 0] + x[:, 1])) \
+        + 0.05 * rng.standard_normal(x.shape[0])
+    xt = torch.tensor(x, dtype=torch.float64, device=dev)
+    x_obs = xt[torch.tensor(obs, device=dev)]
+    mask = np.ones(x.shape[0], bool); mask[obs] = False
+    x_test = xt[torch.tensor(np.nonzero(mask)[0], device=dev)]
+    y_obs = torch.tensor(y[obs], dtype=torch.float64, device=dev)
+    n_obs, n_test = x_obs.shape[0], x_test.shape[0]
+    # factorisation alone
+    A = ops.gram_se(x_obs, x_obs, 1.0, 0.2, 1e-5)
+    A.diagonal().add_(0.05)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    info = ops.potrf_(A, zero_upper=False, nan_on_fail=False)
+    torch.cuda.synchronize(); t_potrf = time.perf_counter() - t0
+    ok = bool((info == 0).all().item())
+    del A
+    xi = ops.randn((n_test,), torch.float64, dev, seed=3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mean, samp, var_out, info = ops.krig_predict(x_obs, x_test, y_obs, 1.0, 0.2, 0.05, 1e-5, xi)
+    torch.cuda.synchronize(); t_pred = time.perf_counter() - t0
+    truth = np.sin(3 * np.pi * x[mask, 0]) + 0.3 * np.cos(9 * np.pi * x[mask, 1]) + 0.5 * np.sin(7 * np.pi * (x[mask, 0] + x[mask, 1]))
+    rmse = float(np.sqrt(np.mean((mean.cpu().numpy() - truth) ** 2)))
+    flop = n_obs ** 3 / 3
+    print(json.dumps({"config": "C4: kriging 192x192 grid, n_obs=32768, n_test=%d, f64" % n_test,
+                      "potrf_s": t_potrf, "potrf_tflops": flop / t_potrf / 1e12, "potrf_frac_of_f64_peak": flop / t_potrf / 1e12 / 78.6,
+                      "pd": ok, "predict_s": t_pred,
+                      "predict_tflops": (flop + n_obs ** 2 * (n_test + 1) + 2 * n_obs * n_test) / t_pred / 1e12,
+                      "rmse_vs_noise_free_truth": rmse, "min_var": float(var_out.min().item()),
+                      "info": int(info.item())}), flush=True)
+
+if "c5" in which:  # potential-gradient evaluations of the VAE-prior regression, 1024 chains
+    n, dims = 300, (35, 30, 10)
+    flat = init_params(n, *dims, 1, torch.float32, dev)
+    dec = decoder_list_from_flat(flat, n, *dims)
+    x = np.arange(0, 1, 1 / n)
+    yv = np.sin(6 * x)
+    obs = [20, 23, 100, 110, 117, 130, 133, 140, 170, 190]
+    inf = VAEInference(None, dec, dims[2], 1, x, yv, obs, {}, dtype=torch.float32)
+    chains = 1024
+    z = ops.randn((chains, dims[2]), torch.float32, dev, seed=5)
+    ls = torch.full((chains,), math.log(0.1), device=dev)
+    t = timed(lambda: inf.potential_and_grad(z, ls), 50)
+    print(json.dumps({"config": "C5: VAE-prior regression potential+gradient, 1024 chains, decoder 10-30-35-300, f32",
+                      "grad_evals_per_s": chains / t, "ms_per_batched_eval": t * 1e3}), flush=True)
+
+if "c4check" in which:  # the same problem on a 64x64 grid against the CPU oracle (literal inverse-based arithmetic)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gpvae_oracle as orc
+    g = np.arange(64) / 64.0
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1)
+    rng = np.random.default_rng(0)
+    obs = np.sort(rng.permutation(x.shape[0])[:3641])
+    f = lambda p: np.sin(3 * np.pi * p[:, 0]) + 0.3 * np.cos(9 * np.pi * p[:, 1]) + 0.5 * np.sin(7 * np.pi * (p[:, 0] + p[:, 1]))
+    y = f(x) + 0.05 * rng.standard_normal(x.shape[0])
+    mask = np.ones(x.shape[0], bool); mask[obs] = False
+    xt = torch.tensor(x, dtype=torch.float64, device=dev)
+    xi = np.zeros(int(mask.sum()))
+    mean, samp, var_out, info = ops.krig_predict(xt[torch.tensor(obs, device=dev)], xt[torch.tensor(np.nonzero(mask)[0], device=dev)],
+                                                 torch.tensor(y[obs], dtype=torch.float64, device=dev), 1.0, 0.2, 0.05, 1e-5,
+                                                 torch.tensor(xi, dtype=torch.float64, device=dev))
+    yy = np.full(x.shape[0], np.nan); yy[obs] = y[obs]
+    m_ref, s_ref, v_ref = orc.gp_prediction(x, yy, obs, 1.0, 0.2, 0.05, xi)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print(json.dumps({"config": "C4 check: 64x64 grid, n_obs=3641, f64, vs oracle.gp_prediction",
+                      "rel_mean": rel(mean.cpu().numpy(), m_ref), "rel_var": rel(var_out.cpu().numpy(), v_ref),
+                      "rmse_gpu": float(np.sqrt(np.mean((mean.cpu().numpy() - f(x[mask])) ** 2))),
+                      "rmse_oracle": float(np.sqrt(np.mean((m_ref - f(x[mask])) ** 2)))}), flush=True)
