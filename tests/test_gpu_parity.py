@@ -326,6 +326,24 @@ def test_vae_elbo_reference_dims(ops, ndt, tdt, tol, dims):
         assert rel(gd[k], go[k]) < t, k
 
 
+def test_vae_elbo_full_size_c3(ops):
+    """The bench shape (B = n = 4096, 50-30-15, fp32) against the oracle: every fast path of the tile
+    products (VALU-free k loops, ragged-K through the buffer range check, TileIO epilogues, split-K
+    atomics) is on at this size.  fp32 tolerance 1e-3 (north_star)."""
+    B, n, h0, h1, z = 4096, 4096, 50, 30, 15
+    rng = np.random.default_rng(11)
+    p = {k: (10 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+    lo, go = orc.elbo_loss_and_grads(p, Y, ez, 0.1)
+    flat = dev(orc.flatten(p), torch.float32)
+    grads = torch.empty_like(flat)
+    loss = ops.vae_elbo(flat, dev(Y, torch.float32), dev(ez, torch.float32), (h0, h1, z), 0.1, grads=grads)
+    assert abs(loss.item() - lo) < 1e-3 * abs(lo)
+    gd = orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+    for k in orc.PARAM_NAMES:
+        assert rel(gd[k], go[k]) < 1e-3, k
+
+
 def test_vaeinference_potential_gradient(ops):
     from gp_vae_amd.inference import VAEInference
     rng = np.random.default_rng(6)
