@@ -48,7 +48,7 @@ template <typename T> struct VRows {
 template <typename T> struct PanelCfg;
 template <> struct PanelCfg<float> {
   static constexpr int BK = 32;  // k-tile of the staged update GEMM
-  static constexpr int NCH = 4;  // 64-row chunks per workgroup (one per wave in the solve)
+  static constexpr int NCH = 2;  // 64-row chunks per workgroup (one per wave in the solve)
   static constexpr int S = 68;   // LDS row stride of the 64-wide blocks (16-B aligned rows,
                                  // ds_read_b128 of one row per lane is conflict free: 17 slots/row)
 };
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   constexpr int VEC = VecT<T>::N;
   constexpr int VPR = NB / VEC;                     // vectors per 64-wide row
   using V = typename VecT<T>::type;
-  static_assert(FM == 2, "chunk rows per wave");
+  static_assert(FM >= 1 && RPW % M::TM == 0, "chunk rows per wave");
   static_assert((SROWS * VPR) % NTHREADS == 0, "copy-in tiling");
 
   __shared__ __align__(16) T Blk[SROWS * S];   // [diag block (64 rows); chunks] row-major, stride S
