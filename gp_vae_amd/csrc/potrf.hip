@@ -233,27 +233,6 @@ __device__ __forceinline__ int window16(T *img, T *Dm, T *rdiag, int W, int lane
   return fail;
 }
 
-// factor the 64x64 block in Dm (one wave, lane = row); returns the first bad pivot column or -1
-template <typename T, int S>
-__device__ __forceinline__ int diag_block16(T *Dm, T *rdiag, int lane, int zoff) {
-  int fail = -1;
-#pragma unroll
-  for (int W = 0; W < NB; W += 16) fail = window16<T, S, true>(Dm, Dm, rdiag, W, lane, zoff, fail);
-  return fail;
-}
-
-// solve X L11^T = C for the 64 rows in Cw (one wave, lane = row), in place
-template <typename T, int S>
-__device__ __forceinline__ void trsm_block16(T *Cw, T *Dm, T *rdiag, int lane, int zoff) {
-  if constexpr (sizeof(T) == 4) {  // measured: f32 is faster unrolled, f64 as a run-time loop
-#pragma unroll
-    for (int W = 0; W < NB; W += 16) window16<T, S, false>(Cw, Dm, rdiag, W, lane, zoff, -1);
-  } else {
-#pragma unroll 1
-    for (int W = 0; W < NB; W += 16) window16<T, S, false>(Cw, Dm, rdiag, W, lane, zoff, -1);
-  }
-}
-
 template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
@@ -384,20 +363,27 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   __syncthreads();
   STAMP(2);
 
-  // ---- (b) factor the diagonal block: wave 0, lane = row ----------------------------------------
-  if (wave == 0) {
-    const int fail = diag_block16<T, S>(Dm, rdiag, lane, zoff);
-    if (blockIdx.x == 0 && lane == 0 && fail >= 0 && c0 + fail < n) {
+  // ---- (b)+(c) factor the diagonal block (wave 3) and solve the chunks (waves 0..NCH-1, one
+  // 64-row chunk each), both lane = row over 16-column windows, pipelined: while wave 3 factors
+  // window w, the solving waves work on window w-1 — a solve window reads columns
+  // [16(w-1), 16w) of L11 (final since the previous phase), the factoring wave touches columns
+  // >= 16w only.  One barrier per phase.
+  static_assert(NCH <= 3, "wave 3 factors the diagonal block");
+  {
+    int fail = -1;
+    const bool solver = wave < NCH && rbase + wave * NB < Mv;
+    T *chunk = &Cw[(wave < NCH ? wave : 0) * NB * S];
+#pragma unroll
+    for (int ph = 0; ph <= NB / 16; ++ph) {
+      if (wave == 3 && ph < NB / 16) fail = window16<T, S, true>(Dm, Dm, rdiag, 16 * ph, lane, zoff, fail);
+      if (solver && ph >= 1) window16<T, S, false>(chunk, Dm, rdiag, 16 * (ph - 1), lane, zoff, -1);
+      __syncthreads();
+    }
+    if (wave == 3 && blockIdx.x == 0 && lane == 0 && fail >= 0 && c0 + fail < n) {
       if (info[b] == 0) info[b] = (int32_t)(c0 + fail + 1);
     }
   }
-  __syncthreads();
   STAMP(3);
-
-  // ---- (c) solve the chunks: one chunk per wave, lane = row -----------------------------------
-  if (wave < NCH && rbase + wave * NB < Mv)
-    trsm_block16<T, S>(&Cw[wave * NB * S], Dm, rdiag, lane, zoff);
-  __syncthreads();
   STAMP(4);
 
   // ---- coalesced stores ---------------------------------------------------------------------------
