@@ -567,7 +567,8 @@ struct PipeKC {
   // one k-tile; CUR compile-time so every LDS offset is an immediate
   template <int CUR, bool FAST>
   __device__ __forceinline__ void tile(LA &la, LB &lb, T *lds, int aoff, int boff, int64_t k,
-                                       int64_t kend, int tid, typename M::acc_t (&acc)[FM][FN]) {
+                                       int64_t kend, int tid, bool compute,
+                                       typename M::acc_t (&acc)[FM][FN]) {
     constexpr int NXT = CUR ^ 1;
     const bool has1 = FAST || k + BK < kend, has2 = FAST || k + 2 * BK < kend;
     if (has1) {
@@ -588,21 +589,27 @@ struct PipeKC {
         lb.load(k + 2 * BK, kend, tid);
       }
     }
-    read_half<CUR, 1>(lds, aoff, boff);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half<0>(acc);
-    __builtin_amdgcn_sched_barrier(0);
+    if (compute) {
+      read_half<CUR, 1>(lds, aoff, boff);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half<0>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
-    if (has1) read_half<NXT, 0>(lds, aoff, boff);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half<1>(acc);
-    __builtin_amdgcn_sched_barrier(0);
+    if (compute) {
+      if (has1) read_half<NXT, 0>(lds, aoff, boff);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
-  // acc += A[am0.., k] B[bn0.., k]^T over k in [kbeg, kend), kbeg < kend; lds holds LDS_ELEMS
+  // acc += A[am0.., k] B[bn0.., k]^T over k in [kbeg, kend), kbeg < kend; lds holds LDS_ELEMS.
+  // compute (wave-uniform) = false: the wave only stages operands and keeps the barriers (its
+  // output tile is not wanted) — its share of the MFMA pipe goes to the other block on the CU.
   __device__ __forceinline__ void run(LA &la, LB &lb, T *lds, int64_t kbeg, int64_t kend, int am0,
                                       int bn0, int lane, int tid,
-                                      typename M::acc_t (&acc)[FM][FN]) {
+                                      typename M::acc_t (&acc)[FM][FN], bool compute = true) {
     kbeg = uniform64(kbeg);
     kend = uniform64(kend);
     int64_t kfast = la.fast_end(kend);
@@ -623,16 +630,16 @@ struct PipeKC {
       lb.load(kbeg + BK, kend, tid);
     }
     __syncthreads();
-    read_half<0, 0>(lds, aoff, boff);
+    if (compute) read_half<0, 0>(lds, aoff, boff);
     int64_t k = kbeg;
     for (int i = 0; i < npairs; ++i, k += 2 * BK) {
-      tile<0, true>(la, lb, lds, aoff, boff, k, kend, tid, acc);
-      tile<1, true>(la, lb, lds, aoff, boff, k + BK, kend, tid, acc);
+      tile<0, true>(la, lb, lds, aoff, boff, k, kend, tid, compute, acc);
+      tile<1, true>(la, lb, lds, aoff, boff, k + BK, kend, tid, compute, acc);
     }
     const int nrest = (int)((kend - k + BK - 1) / BK);
     for (int i = 0; i < nrest; i += 2, k += 2 * BK) {
-      tile<0, false>(la, lb, lds, aoff, boff, k, kend, tid, acc);
-      if (i + 1 < nrest) tile<1, false>(la, lb, lds, aoff, boff, k + BK, kend, tid, acc);
+      tile<0, false>(la, lb, lds, aoff, boff, k, kend, tid, compute, acc);
+      if (i + 1 < nrest) tile<1, false>(la, lb, lds, aoff, boff, k + BK, kend, tid, compute, acc);
     }
   }
 };

@@ -484,9 +484,11 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_k
 #pragma unroll
       for (int r = 0; r < M::NACC; ++r) acc[fm][fn][r] = -acc[fm][fn][r];
   Pipe pipe;
-  pipe.run(la, lb, lds, cJ, kend, wm, wn, lane, tid, acc);
-  // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: nothing to store
-  if (diag_tile && wm == 0 && wn == 64) return;
+  // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: it stages operands
+  // and keeps the barriers but issues no MFMA
+  const bool wanted = !(diag_tile && wm == 0 && wn == 64);
+  pipe.run(la, lb, lds, cJ, kend, wm, wn, lane, tid, acc, wanted);
+  if (!wanted) return;
   if (interior) {
 #pragma unroll
     for (int fm = 0; fm < F; ++fm)
