@@ -88,14 +88,29 @@ class GPInference(Inference):
         var = np.asarray(post_samples["kernel_var"], dtype=np.float64)
         ls = np.asarray(post_samples["kernel_length"], dtype=np.float64)
         sig = np.asarray(post_samples["kernel_sigma"], dtype=np.float64)
-        mine = shard(var.shape[0])
+        mine = np.asarray(list(shard(var.shape[0])), dtype=np.int64)
         base = _seed_of(rng_key)
+        x_obs, x_test = self._split()
+        n_obs, n_test = x_obs.shape[0], x_test.shape[0]
+        y_obs = self.y[self.obs_idx]
+        # batches sized to ~4 GiB of workspace: one batched Gram + factorisation + finish each
+        per = max(1, min(len(mine), 16384, int(2 ** 32 // max(1, (n_obs + n_test + 2) * n_obs * 8))))
         means, preds = [], []
-        for s in mine:
-            m, p = self.gp_prediction(base + s, self.x, self.y, var[s], ls[s], sig[s])
+        self.last_info = []
+        for lo in range(0, len(mine), per):
+            idx = mine[lo:lo + per]
+            # draw s keeps the normals it had one problem at a time: seed base + s, stream 0xC41
+            xi = torch.stack([ops.randn((n_test,), self.dtype, self.x.device, seed=base + int(s),
+                                        stream_id=0xC41) for s in idx]) if n_test else None
+            m, p, _, info = ops.krig_predict_batched(x_obs, x_test, y_obs, var[idx], ls[idx], sig[idx],
+                                                     1.0e-5, xi)
             means.append(m)
             preds.append(p)
-        return torch.stack(means), torch.stack(preds)
+            self.last_info.append(info)
+        if not means:
+            e = torch.empty((0, n_test), dtype=self.dtype, device=self.x.device)
+            return e, e.clone()
+        return torch.cat(means), torch.cat(preds)
 
 
 class VAEInference(Inference):

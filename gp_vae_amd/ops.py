@@ -183,6 +183,39 @@ def krig_predict(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi=None):
     return mean, samp, vout, info
 
 
+def krig_predict_batched(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi=None):
+    """krig_predict for a batch of hyper-parameter draws sharing points and observations
+    (the vmap of inference.py:517-521).  var, ls, sigma: 1-D [S]; xi: [S, n_test] or None.
+    Returns mean, sample, var: [S, n_test] and info int32[S]."""
+    _dev(x_obs, x_test, y_obs, xi)
+    x_obs, x_test = _points(x_obs), _points(x_test)
+    n_obs, n_test, d = x_obs.shape[0], x_test.shape[0], x_obs.shape[1]
+    dt, dv = x_obs.dtype, x_obs.device
+    var_t = torch.as_tensor(var, dtype=dt, device=dv).reshape(-1).contiguous()
+    ls_t = torch.as_tensor(ls, dtype=dt, device=dv).reshape(-1).contiguous()
+    sig_t = torch.as_tensor(sigma, dtype=dt, device=dv).reshape(-1).contiguous()
+    S = var_t.numel()
+    if ls_t.numel() != S or sig_t.numel() != S:
+        raise GpvaeError("krig_predict_batched: var, ls, sigma need the same length")
+    if xi is not None:
+        xi = xi.contiguous()
+        if tuple(xi.shape) != (S, n_test):
+            raise GpvaeError("krig_predict_batched: xi must be [S, n_test]")
+    y_obs = y_obs.contiguous()
+    lib = _lib.load()
+    nbytes = lib.gpvae_krig_batched_workspace_bytes(_dt(x_obs), n_obs, n_test, S)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dv)
+    mean = torch.empty((S, n_test), dtype=dt, device=dv)
+    samp = torch.empty_like(mean)
+    vout = torch.empty_like(mean)
+    info = torch.empty(S, dtype=torch.int32, device=dv)
+    check(lib.gpvae_krig_predict_batched(_stream(), _dt(x_obs), d, n_obs, n_test, S, _p(x_obs),
+                                         _p(x_test), _p(y_obs), _p(var_t), _p(ls_t), _p(sig_t),
+                                         float(jitter), _p(xi), _p(mean), _p(samp), _p(vout),
+                                         _p(info), _p(work)), "gpvae_krig_predict_batched")
+    return mean, samp, vout, info
+
+
 # ---- a5-a7, a11: VAE -----------------------------------------------------------------------------------
 def vae_param_count(n, h0, h1, z):
     return int(_lib.load().gpvae_vae_param_count(n, h0, h1, z))

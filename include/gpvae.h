@@ -111,6 +111,20 @@ int gpvae_krig_predict(void *stream, int dtype, int d, int64_t n_obs, int64_t n_
                        const void *ls, const void *sigma, double jitter, const void *xi, void *mean,
                        void *sample, void *var_out, int32_t *info, void *work);
 
+/* ---- f2: the same prediction for a batch of hyper-parameter draws ----------------------------------
+ * Replaces the vmap of gp_prediction over posterior samples in GPInference.gp_fit
+ * (src/model/inference.py:511-521): the points and observations are shared, problem b has its own
+ * var[b], ls[b], sigma[b] (device arrays of `batch`) and normals xi[b][n_test] (NULL => sample =
+ * mean).  Outputs mean, sample, var_out: [batch][n_test]; info: int32[batch].  One batched Gram
+ * build, ONE batched factorisation with the k_px rows and y riding along, one finishing pass.
+ * work: gpvae_krig_batched_workspace_bytes() bytes (about batch*(n_obs + n_test + 1)*n_obs*s).     */
+int64_t gpvae_krig_batched_workspace_bytes(int dtype, int64_t n_obs, int64_t n_test, int batch);
+int gpvae_krig_predict_batched(void *stream, int dtype, int d, int64_t n_obs, int64_t n_test,
+                               int batch, const void *x_obs, const void *x_test, const void *y_obs,
+                               const void *var, const void *ls, const void *sigma, double jitter,
+                               const void *xi, void *mean, void *sample, void *var_out,
+                               int32_t *info, void *work);
+
 /* ---- a5+a6: VAE ELBO forward (+ backward) ---------------------------------------------------------
  * Replaces vae_encoder/vae_decoder (src/model/vae.py:72-96) and vae_model+vae_guide under
  * Trace_ELBO (vae.py:98-137,213-218): one-particle ELBO summed over batch and dims, obs noise

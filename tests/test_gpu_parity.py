@@ -281,6 +281,35 @@ def test_gpinference_surface(ops, golden):
     means, preds = inf.gp_fit_from_samples(1, post)
     assert means.shape == (2, 290)
     assert rel(means[1], orc.gp_prediction(g["krig_x"], g["krig_y"], g["krig_obs"], 1.1, 0.1, 0.05)[0]) < 1e-8
+    # the batched sweep gives every draw what gp_prediction gives it alone (same normals too)
+    m1, p1 = inf.gp_prediction(1 + 1, inf.x, inf.y, 1.1, 0.1, 0.05)
+    assert rel(means[1], m1.cpu().numpy()) < 1e-12 and rel(preds[1], p1.cpu().numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_kriging_batched(ops, ndt, tdt, tol):
+    """f2: S hyper-parameter draws in one call against the oracle's literal arithmetic per draw,
+    1-D and 2-D points, a non-PD problem in the middle of the batch (info > 0, NaN outputs)."""
+    rng = np.random.default_rng(21)
+    for d, n, n_obs in ((1, 150, 37), (2, 144, 100)):
+        x = np.arange(n) / n if d == 1 else np.stack(np.meshgrid(np.arange(12) / 12, np.arange(12) / 12), -1).reshape(-1, 2)
+        obs = np.sort(rng.permutation(n)[:n_obs])
+        y = np.full(n, np.nan)
+        y[obs] = np.sin(5 * (x[obs] if d == 1 else x[obs].sum(1))) + 0.1 * rng.standard_normal(n_obs)
+        mask = np.ones(n, bool); mask[obs] = False
+        S = 5
+        var = rng.uniform(0.5, 1.5, S); ls = rng.uniform(0.05, 0.3, S); sig = rng.uniform(0.01, 0.1, S)
+        sig[2] = -10.0  # A = K + sigma I not positive definite
+        xi = rng.standard_normal((S, n - n_obs))
+        m, p, v, info = ops.krig_predict_batched(dev(x[obs].astype(ndt), tdt), dev(x[mask].astype(ndt), tdt), dev(y[obs], tdt),
+                                                 var, ls, sig, 1e-5, dev(xi, tdt))
+        info = info.cpu().numpy()
+        assert info[2] > 0 and (np.delete(info, 2) == 0).all()
+        assert np.isnan(m[2].cpu().numpy()).all()
+        for s in (0, 1, 3, 4):
+            mo, po, vo = orc.gp_prediction(x.astype(ndt), y.astype(ndt), obs, ndt(var[s]), ndt(ls[s]), ndt(sig[s]), xi[s].astype(ndt))
+            t = tol * 50 if ndt == np.float32 else 1e-7
+            assert rel(m[s], mo) < t and rel(p[s], po) < t, (d, s)
 
 
 # ---- a5/a6/a7/a11 --------------------------------------------------------------------------------------------

@@ -113,3 +113,35 @@ if "c4check" in which:  # the same problem on a 64x64 grid against the CPU oracl
                       "rel_mean": rel(mean.cpu().numpy(), m_ref), "rel_var": rel(var_out.cpu().numpy(), v_ref),
                       "rmse_gpu": float(np.sqrt(np.mean((mean.cpu().numpy() - f(x[mask])) ** 2))),
                       "rmse_oracle": float(np.sqrt(np.mean((m_ref - f(x[mask])) ** 2)))}), flush=True)
+
+if "f2" in which:  # batched small kriging: the reference's vmap over posterior samples (inference.py:511-521)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gpvae_oracle as orc
+    g = np.arange(25) / 25.0
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1).astype(np.float32)      # 25x25 grid (2d_examples.py scale)
+    rng = np.random.default_rng(0)
+    for n_obs in (100, 400):
+        obs = np.sort(rng.permutation(x.shape[0])[:n_obs])
+        mask = np.ones(x.shape[0], bool); mask[obs] = False
+        y = np.sin(4 * x.sum(1)) + 0.1 * rng.standard_normal(x.shape[0])
+        S = 8000
+        var = rng.lognormal(0, 0.1, S); ls = rng.uniform(0.05, 0.5, S); sig = np.abs(rng.normal(0, 0.1, S)) + 1e-3
+        xo = torch.tensor(x[obs], device=dev); xt = torch.tensor(x[mask], device=dev)
+        yo = torch.tensor(y[obs], dtype=torch.float32, device=dev)
+        xi = ops.randn((S, int(mask.sum())), torch.float32, dev, seed=9)
+        t = timed(lambda: ops.krig_predict_batched(xo, xt, yo, var, ls, sig, 1e-5, xi), 3)
+        m, p, vv, info = ops.krig_predict_batched(xo, xt, yo, var, ls, sig, 1e-5, xi)
+        nl = 100
+        tl = timed(lambda: [ops.krig_predict(xo, xt, yo, float(var[s]), float(ls[s]), float(sig[s]), 1e-5, xi[s]) for s in range(nl)], 1) / nl
+        yy = np.full(x.shape[0], np.nan, np.float32); yy[obs] = y[obs]
+        t0 = time.perf_counter()
+        for s in range(10):
+            mo = orc.gp_prediction(x, yy, obs, np.float32(var[s]), np.float32(ls[s]), np.float32(sig[s]))[0]
+        tc = (time.perf_counter() - t0) / 10
+        err = float(np.linalg.norm(m[9].cpu().numpy() - mo) / np.linalg.norm(mo))
+        flop = S * (n_obs ** 3 / 3 + n_obs ** 2 * (int(mask.sum()) + 1))
+        print(json.dumps({"config": "f2: batched kriging, 25x25 grid, n_obs=%d, n_test=%d, S=%d draws, f32" % (n_obs, int(mask.sum()), S),
+                          "problems_per_s": S / t, "ms_total": t * 1e3, "tflops": flop / t / 1e12,
+                          "one_at_a_time_problems_per_s": 1 / tl, "cpu_oracle_problems_per_s": 1 / tc,
+                          "pd_fraction": float((info == 0).float().mean().item()), "rel_err_vs_oracle_draw9": err}), flush=True)
