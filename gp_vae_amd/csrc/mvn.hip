@@ -1,0 +1,231 @@
+// mvn.hip — zero-mean multivariate-normal log-density with a squared-exponential covariance, and its
+// gradient.
+//
+// Replaces what NUTS differentiates in GPInference.gp_regression
+// (/root/reference/src/model/inference.py:400-424): k = kernel(x, x, var, ls) (jitter 1e-5 on the
+// diagonal), f ~ MultivariateNormal(0, k).  For a batch of chains b (own f_b, var_b, ls_b, shared x):
+//   logp  = -1/2 |L^-1 f|^2 - sum_i log L_ii - n/2 log 2 pi                    K = L L^T
+//   dlogp/df   = -alpha,                      alpha = K^-1 f
+//   dlogp/dvar = 1/(2 var)   sum_ij G_ij K0_ij,       G = alpha alpha^T - K^-1,  K0 = K - jitter I
+//   dlogp/dls  = 1/(2 ls^3)  sum_ij G_ij K0_ij r_ij^2,       r_ij = |x_i - x_j|
+// The reference gets these by reverse-mode through jnp.linalg.cholesky; here they are closed form.
+//
+// One batched Gram build, ONE batched gpvae_potrf with n+1 extra rows [I; f^T]: the rows come back as
+// U = L^-T and w^T = (L^-1 f)^T, so K^-1 = U U^T and alpha = U w need no further triangular solve.
+// mvn_finish_kernel (one wave per row): alpha, -alpha -> grad_f, the three terms of logp.
+// mvn_grad_kernel: 128x128 tiles of U U^T on the MFMA pipeline (PipeKC, both operands K-contiguous
+// rows of U), epilogue G_ij K0_ij (1, r^2) with K0 recomputed from the points, reduced to two scalars
+// per chain.  Bound: MFMA (n^3 flop per chain for U U^T, n^3 for the ride-along solve, n^3/3 factor).
+#include "gemm_core.hpp"
+
+namespace gpvae {
+
+template <typename T> __device__ __forceinline__ T dlog(T v);
+template <> __device__ __forceinline__ float dlog<float>(float v) { return logf(v); }
+template <> __device__ __forceinline__ double dlog<double>(double v) { return log(v); }
+
+struct MvnWork {
+  int64_t lda, a_elems, x_elems;
+};
+static inline MvnWork mvn_layout(int64_t n) {
+  MvnWork w;
+  w.lda = round_up(n, 4);
+  w.a_elems = n * w.lda;
+  w.x_elems = (n + 1) * w.lda;
+  return w;
+}
+
+// X_b = [I_n ; f_b^T]; logp_b = -n/2 log 2pi; the two gradient accumulators = 0.  grid (rows, batch)
+template <typename T>
+__global__ void mvn_fill_kernel(int64_t n, T *X, int64_t ldx, int64_t strideX, const T *f, T *logp,
+                                T *acc2) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = blockIdx.x;  // row 0..n
+  T *row = X + b * strideX + i * ldx;
+  for (int64_t k = threadIdx.x; k < n; k += blockDim.x)
+    row[k] = (i < n) ? (k == i ? T(1) : T(0)) : f[b * n + k];
+  if (i == 0 && threadIdx.x == 0) {
+    logp[b] = T(-0.9189385332046727) * (T)n;
+    acc2[2 * b] = T(0);
+    acc2[2 * b + 1] = T(0);
+  }
+}
+
+// one wave per row i: alpha_i = U[i,:] . w ; logp -= log L_ii + w_i^2 / 2.  grid (ceil(n/4), batch)
+template <typename T>
+__global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, int64_t lda,
+                                                         int64_t strideA, const T *X, int64_t ldx,
+                                                         int64_t strideX, const int32_t *info,
+                                                         T *alpha, T *grad_f, T *logp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t b = blockIdx.y;
+  if (i >= n) return;
+  const T *U = X + b * strideX;
+  const T *w = U + n * ldx;
+  T dot = T(0);
+  for (int64_t k = i + lane; k < n; k += 64) dot += U[i * ldx + k] * w[k];  // U is upper triangular
+  dot = wave_sum<T>(dot);
+  if (lane == 0) {
+    const bool bad = info[b] != 0;
+    const T a = bad ? dnan<T>() : dot;
+    alpha[b * n + i] = a;
+    if (grad_f) grad_f[b * n + i] = -a;
+    const T lii = A[b * strideA + i * lda + i];
+    atomicAdd(&logp[b], bad ? dnan<T>() : -(dlog<T>(lii) + T(0.5) * w[i] * w[i]));
+  }
+}
+
+// tiles of K^-1 = U U^T against K0 and K0 r^2.  grid (tiles, tiles, batch)
+template <typename T, int D, bool VECM>
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void mvn_grad_kernel(
+    int64_t n, const T *X, int64_t ldx, int64_t strideX, const T *x, const T *var_p, const T *ls_p,
+    const T *alpha, T *acc2) {
+  using M = Mfma<T>;
+  constexpr int BM = 128, BK = TileK<T>::BK, F = 64 / M::TM;
+  using LA = LoaderKC<T, BM, BK, VECM>;
+  using Pipe = PipeKC<T, F, F, BK, BM, BM, LA, LA>;
+  __shared__ __align__(16) T lds[Pipe::LDS_ELEMS];
+  __shared__ T red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.z;
+  const T *U = X + b * strideX;
+  const int64_t r0 = (int64_t)blockIdx.x * BM, q0 = (int64_t)blockIdx.y * BM;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  // U[i][k] = 0 for k < i: the product only needs k >= max(r0, q0), rounded down to a k-tile
+  const int64_t kmin = (r0 > q0 ? r0 : q0) / BK * BK;
+
+  LA la, lb;
+  la.init([&](int s, int64_t &rg) -> const T * { rg = r0 + s; return (r0 + s < n) ? U + (r0 + s) * ldx : nullptr; }, U, tid);
+  lb.init([&](int s, int64_t &rg) -> const T * { rg = q0 + s; return (q0 + s < n) ? U + (q0 + s) * ldx : nullptr; }, U, tid);
+  typename M::acc_t acc[F][F];
+  zero_acc<T, F, F>(acc);
+  Pipe pipe;
+  if (kmin < n) pipe.run(la, lb, lds, kmin, n, wm, wn, lane, tid, acc);
+
+  const T var = var_p[b], ls = ls_p[b];
+  T s1 = T(0), s2 = T(0);
+#pragma unroll
+  for (int fn = 0; fn < F; ++fn) {
+    const int64_t j = q0 + wn + fn * M::TM + M::col(lane);
+    const bool jin = j < n;
+    T xj[D], aj = jin ? alpha[b * n + j] : T(0);
+#pragma unroll
+    for (int e = 0; e < D; ++e) xj[e] = x[(jin ? j : 0) * D + e];
+#pragma unroll
+    for (int fm = 0; fm < F; ++fm)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t i = r0 + wm + fm * M::TM + M::row(lane, r);
+        const bool in = jin && i < n;
+        T d2 = T(0);
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+          const T dl = x[(in ? i : 0) * D + e] - xj[e];
+          d2 += dl * dl;
+        }
+        const T q = dsqrt<T>(d2) / ls;  // the Gram kernel's own arithmetic (gp.py:74-77)
+        const T k0 = var * dexp<T>(T(-0.5) * (q * q));
+        const T g = in ? (alpha[b * n + (in ? i : 0)] * aj - acc[fm][fn][r]) * k0 : T(0);
+        s1 += g;
+        s2 += g * d2;
+      }
+  }
+  s1 = wave_sum<T>(s1);
+  s2 = wave_sum<T>(s2);
+  if (lane == 0) {
+    red[wave] = s1;
+    red[4 + wave] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&acc2[2 * b], red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&acc2[2 * b + 1], red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+// grad_var = s1 / (2 var), grad_ls = s2 / (2 ls^3); NaN when the factorisation failed
+template <typename T>
+__global__ void mvn_scale_kernel(int batch, const T *var, const T *ls, const int32_t *info,
+                                 const T *acc2, T *grad_var, T *grad_ls) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const bool bad = info[b] != 0;
+  if (grad_var) grad_var[b] = bad ? dnan<T>() : acc2[2 * b] / (T(2) * var[b]);
+  if (grad_ls) grad_ls[b] = bad ? dnan<T>() : acc2[2 * b + 1] / (T(2) * ls[b] * ls[b] * ls[b]);
+}
+
+template <typename T>
+static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const void *x,
+                   const void *f, const void *var, const void *ls, double jitter, void *logp,
+                   void *grad_f, void *grad_var, void *grad_ls, int32_t *info, void *work) {
+  const MvnWork w = mvn_layout(n);
+  T *A = (T *)work;                         // [batch][n][lda]
+  T *X = A + (int64_t)batch * w.a_elems;    // [batch][n + 1][lda]
+  T *alpha = X + (int64_t)batch * w.x_elems;  // [batch][n]
+  T *acc2 = alpha + (int64_t)batch * n;       // [batch][2]
+  char *pw = (char *)(acc2 + 2 * (int64_t)batch);
+  pw = (char *)(((uintptr_t)pw + 15) & ~(uintptr_t)15);
+  int rc = gpvae_gram_se((void *)st, dtype, d, n, n, x, x, batch, var, ls, jitter, A, w.lda, w.a_elems);
+  if (rc) return rc;
+  hipLaunchKernelGGL((mvn_fill_kernel<T>), dim3((unsigned)(n + 1), (unsigned)batch), dim3(256), 0, st,
+                     n, X, w.lda, w.x_elems, (const T *)f, (T *)logp, acc2);
+  rc = gpvae_potrf((void *)st, dtype, n, batch, A, w.lda, w.a_elems, n + 1, X, w.lda, w.x_elems, info,
+                   0, pw);
+  if (rc) return rc;
+  hipLaunchKernelGGL((mvn_finish_kernel<T>), dim3((unsigned)cdiv(n, 4), (unsigned)batch), dim3(256),
+                     0, st, n, A, w.lda, w.a_elems, X, w.lda, w.x_elems, info, alpha, (T *)grad_f,
+                     (T *)logp);
+  if (grad_var || grad_ls) {
+    const dim3 grid((unsigned)cdiv(n, 128), (unsigned)cdiv(n, 128), (unsigned)batch);
+    const bool vec = kc_vec_ok<T>(X, w.lda) && (w.x_elems % VecT<T>::N) == 0;
+    auto launch = [&](auto dd, auto vv) {
+      hipLaunchKernelGGL((mvn_grad_kernel<T, decltype(dd)::value, decltype(vv)::value>), grid,
+                         dim3(NTHREADS), 0, st, n, X, w.lda, w.x_elems, (const T *)x, (const T *)var,
+                         (const T *)ls, alpha, acc2);
+    };
+    if (d == 1) {
+      if (vec) launch(std::integral_constant<int, 1>{}, std::true_type{});
+      else launch(std::integral_constant<int, 1>{}, std::false_type{});
+    } else {
+      if (vec) launch(std::integral_constant<int, 2>{}, std::true_type{});
+      else launch(std::integral_constant<int, 2>{}, std::false_type{});
+    }
+    hipLaunchKernelGGL((mvn_scale_kernel<T>), dim3((unsigned)cdiv(batch, 256)), dim3(256), 0, st, batch,
+                       (const T *)var, (const T *)ls, info, acc2, (T *)grad_var, (T *)grad_ls);
+  }
+  GPVAE_CHECK_LAUNCH("gpvae_mvn_logp");
+  return 0;
+}
+
+}  // namespace gpvae
+
+using namespace gpvae;
+
+extern "C" int64_t gpvae_mvn_workspace_bytes(int dtype, int64_t n, int batch) {
+  if (n <= 0 || batch <= 0) return 0;
+  const MvnWork w = mvn_layout(n);
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  return (int64_t)batch * (w.a_elems + w.x_elems + n + 2) * es + 256 +
+         gpvae_potrf_workspace_bytes(dtype, n, n + 1, batch);
+}
+
+extern "C" int gpvae_mvn_logp(void *stream, int dtype, int d, int64_t n, int batch, const void *x,
+                              const void *f, const void *var, const void *ls, double jitter,
+                              void *logp, void *grad_f, void *grad_var, void *grad_ls,
+                              int32_t *info, void *work) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_mvn_logp: bad dtype %d", dtype);
+  GPVAE_REQUIRE(d == 1 || d == 2, 3, "gpvae_mvn_logp: d must be 1 or 2");
+  GPVAE_REQUIRE(n >= 1, 4, "gpvae_mvn_logp: n < 1");
+  GPVAE_REQUIRE(batch >= 0 && batch <= 65535, 5, "gpvae_mvn_logp: batch out of range [0,65535]");
+  if (batch == 0) return 0;
+  GPVAE_REQUIRE(x && f && var && ls, 6, "gpvae_mvn_logp: NULL input");
+  GPVAE_REQUIRE(logp, 11, "gpvae_mvn_logp: logp is NULL");
+  GPVAE_REQUIRE(info, 15, "gpvae_mvn_logp: info is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 16, "gpvae_mvn_logp: work NULL or not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32 ? run_mvn<float>(st, dtype, d, n, batch, x, f, var, ls, jitter, logp,
+                                             grad_f, grad_var, grad_ls, info, work)
+                            : run_mvn<double>(st, dtype, d, n, batch, x, f, var, ls, jitter, logp,
+                                              grad_f, grad_var, grad_ls, info, work);
+}

@@ -216,6 +216,36 @@ def krig_predict_batched(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi
     return mean, samp, vout, info
 
 
+# ---- a10 / f1: MVN log-density and gradient ---------------------------------------------------------
+def mvn_logp(x, f, var, ls, jitter=1.0e-5, grad=True):
+    """log N(f_b; 0, K(x; var_b, ls_b) + jitter I) for a batch of chains, with d/df, d/dvar, d/dls.
+
+    x: [n] or [n,d]; f: [S,n] (or [n]); var, ls: [S] (or scalars).
+    Returns (logp [S], grad_f [S,n], grad_var [S], grad_ls [S], info int32[S]); gradients None if
+    grad=False."""
+    _dev(x, f)
+    x = _points(x)
+    n, d = x.shape
+    dt, dv = x.dtype, x.device
+    f = f.reshape(-1, n).contiguous()
+    S = f.shape[0]
+    var_t = torch.as_tensor(var, dtype=dt, device=dv).reshape(-1).contiguous()
+    ls_t = torch.as_tensor(ls, dtype=dt, device=dv).reshape(-1).contiguous()
+    if var_t.numel() != S or ls_t.numel() != S:
+        raise GpvaeError("mvn_logp: var and ls need one entry per row of f")
+    lib = _lib.load()
+    work = torch.empty(lib.gpvae_mvn_workspace_bytes(_dt(x), n, S), dtype=torch.uint8, device=dv)
+    logp = torch.empty(S, dtype=dt, device=dv)
+    info = torch.empty(S, dtype=torch.int32, device=dv)
+    gf = torch.empty((S, n), dtype=dt, device=dv) if grad else None
+    gv = torch.empty(S, dtype=dt, device=dv) if grad else None
+    gl = torch.empty(S, dtype=dt, device=dv) if grad else None
+    check(lib.gpvae_mvn_logp(_stream(), _dt(x), d, n, S, _p(x), _p(f), _p(var_t), _p(ls_t),
+                             float(jitter), _p(logp), _p(gf), _p(gv), _p(gl), _p(info), _p(work)),
+          "gpvae_mvn_logp")
+    return logp, gf, gv, gl, info
+
+
 # ---- a5-a7, a11: VAE -----------------------------------------------------------------------------------
 def vae_param_count(n, h0, h1, z):
     return int(_lib.load().gpvae_vae_param_count(n, h0, h1, z))

@@ -125,6 +125,21 @@ int gpvae_krig_predict_batched(void *stream, int dtype, int d, int64_t n_obs, in
                                const void *xi, void *mean, void *sample, void *var_out,
                                int32_t *info, void *work);
 
+/* ---- a10 / f1: MVN log-density with squared-exponential covariance, and its gradient ---------------
+ * Replaces what NUTS differentiates in GPInference.gp_regression (src/model/inference.py:400-424):
+ *   k = kernel(x, x, var, ls) (+ jitter I);  f ~ MultivariateNormal(0, k)     (inference.py:414-422)
+ * for a batch of chains: x [n,d] shared, f [batch][n], var[batch], ls[batch] (device arrays).
+ *   logp[b]     = log N(f_b; 0, K_b)
+ *   grad_f      [batch][n]  = -K^-1 f          (may be NULL)
+ *   grad_var[b], grad_ls[b] = d logp / d var, d logp / d ls   (closed form; may be NULL)
+ * info: int32[batch] potrf status; a chain whose K is not positive definite gets NaN outputs.
+ * work: gpvae_mvn_workspace_bytes() bytes (about batch*(2n+1)*n*s).  The reference obtains the
+ * gradient by reverse-mode through jnp.linalg.cholesky; values agree, the arithmetic differs.     */
+int64_t gpvae_mvn_workspace_bytes(int dtype, int64_t n, int batch);
+int gpvae_mvn_logp(void *stream, int dtype, int d, int64_t n, int batch, const void *x,
+                   const void *f, const void *var, const void *ls, double jitter, void *logp,
+                   void *grad_f, void *grad_var, void *grad_ls, int32_t *info, void *work);
+
 /* ---- a5+a6: VAE ELBO forward (+ backward) ---------------------------------------------------------
  * Replaces vae_encoder/vae_decoder (src/model/vae.py:72-96) and vae_model+vae_guide under
  * Trace_ELBO (vae.py:98-137,213-218): one-particle ELBO summed over batch and dims, obs noise

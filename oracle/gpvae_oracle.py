@@ -180,6 +180,32 @@ def gp_prediction(x, y, obs_idx, var, ls, sigma, xi=None, jitter=1.0e-5, kernel=
 
 
 # --------------------------------------------------------------------------------------------------
+# a10 / f1  log N(f; 0, k) of gp_regression (src/model/inference.py:414-422) and its gradient
+# --------------------------------------------------------------------------------------------------
+def mvn_logp(x, f, var, ls, jitter=1.0e-5, kernel=exp_kernel2):
+    """log MultivariateNormal(0, kernel(x, x, var, ls)).log_prob(f)  (inference.py:414,417-422)."""
+    K = kernel(x, x, var, ls, jitter)
+    L = cholesky_lower(K)
+    w = sla.solve_triangular(L, np.asarray(f, K.dtype), lower=True)
+    n = K.shape[0]
+    return float(-0.5 * w @ w - np.log(np.diag(L)).sum() - 0.5 * n * np.log(2 * np.pi))
+
+
+def mvn_logp_grads(x, f, var, ls, jitter=1.0e-5):
+    """(logp, dlogp/df [n], dlogp/dvar, dlogp/dls): closed form of what reverse-mode through
+    jnp.linalg.cholesky gives NUTS:  G = 1/2 (alpha alpha^T - K^-1),  d/dtheta = sum G * dK/dtheta."""
+    x2 = _col(x)
+    K = exp_kernel2(x, x, var, ls, jitter)
+    n = K.shape[0]
+    K0 = K - jitter * np.eye(n, dtype=K.dtype)
+    Kinv = np.linalg.inv(K)
+    alpha = Kinv @ np.asarray(f, K.dtype)
+    G = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    D2 = ((x2[:, None, :] - x2[None, :, :]) ** 2).sum(-1)
+    return mvn_logp(x, f, var, ls, jitter), -alpha, float((G * K0).sum() / var), float((G * K0 * D2).sum() / ls ** 3)
+
+
+# --------------------------------------------------------------------------------------------------
 # a5/a6  stax encoder/decoder + Trace_ELBO loss  (src/model/vae.py:72-137, 213-218)
 # --------------------------------------------------------------------------------------------------
 

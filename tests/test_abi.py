@@ -20,7 +20,7 @@ def header_symbols():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = header_symbols()
-    assert len(names) == 19
+    assert len(names) == 21
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name

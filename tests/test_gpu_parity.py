@@ -312,6 +312,31 @@ def test_kriging_batched(ops, ndt, tdt, tol):
             assert rel(m[s], mo) < t and rel(p[s], po) < t, (d, s)
 
 
+# ---- a10 / f1 ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_mvn_logp_and_gradient(ops, ndt, tdt, tol):
+    """Batch of chains against the oracle's closed form (itself pinned to SciPy and finite differences
+    in tests/test_oracle.py); 1-D and 2-D points, sizes that are not tile multiples, one chain whose
+    K is not positive definite."""
+    rng = np.random.default_rng(8)
+    for x in (np.arange(150) / 150.0, rng.uniform(0, 1, (300, 2)), np.arange(37) / 37.0):
+        n = x.shape[0]
+        S = 4
+        var = rng.uniform(0.7, 1.4, S); ls = rng.uniform(0.1, 0.3, S)
+        jit = 1e-5 if ndt == np.float64 else 1e-3   # fp32: keep cond(K) within reach of the type
+        F = np.stack([np.linalg.cholesky(orc.exp_kernel2(x, x, var[s], ls[s], jit)) @ rng.standard_normal(n) for s in range(S)])
+        var_bad = var.copy(); var_bad[2] = -1.0
+        lp, gf, gv, gl, info = ops.mvn_logp(dev(x.astype(ndt), tdt), dev(F, tdt), var_bad, ls, jit)
+        info = info.cpu().numpy()
+        assert info[2] > 0 and np.isnan(lp[2].item()) and np.isnan(gv[2].item())
+        for s in (0, 1, 3):
+            lo, gfo, gvo, glo = orc.mvn_logp_grads(x, F[s], var[s], ls[s], jit)
+            t = 1e-7 if ndt == np.float64 else 2e-2
+            assert abs(lp[s].item() - lo) < t * abs(lo), (n, s)
+            assert rel(gf[s], gfo) < t, (n, s)
+            assert abs(gv[s].item() - gvo) < t * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < t * max(1.0, abs(glo)), (n, s)
+
+
 # ---- a5/a6/a7/a11 --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
 def test_vae_elbo_adam_decoder_golden(ops, golden, ndt, tdt, tol):

@@ -219,3 +219,26 @@ def test_hyper_priors_have_the_right_moments():
     assert abs(np.median(d[:, 0]) - 0.1 / np.log(2)) < 0.01  # InverseGamma(1, .1) median
     assert abs(np.mean(np.log(d[:, 1]))) < 0.005 and abs(np.std(np.log(d[:, 1])) - 0.1) < 0.005
     assert abs(np.mean(d[:, 2]) - 0.1 * np.sqrt(2 / np.pi)) < 0.002  # HalfNormal(0.1) mean
+
+
+def test_mvn_logp_matches_scipy_and_finite_differences():
+    """f1 oracle pins: scipy.stats.multivariate_normal.logpdf and central
+    finite differences of the closed-form gradient."""
+    import scipy.stats
+    rng = np.random.default_rng(3)
+    for x in (np.arange(40) / 40.0, rng.uniform(0, 1, (30, 2))):
+        n = x.shape[0]
+        var, ls = 1.3, 0.21
+        jit = 1e-3  # keeps cond(K) ~1e4 so that central differences are meaningful
+        K = orc.exp_kernel2(x, x, var, ls, jit)
+        f = np.linalg.cholesky(K) @ rng.standard_normal(n)
+        lp, gf, gv, gl = orc.mvn_logp_grads(x, f, var, ls, jit)
+        want = scipy.stats.multivariate_normal(np.zeros(n), K, allow_singular=False).logpdf(f)
+        assert abs(lp - want) < 1e-8 * abs(want)
+        h = 1e-5
+        fd_v = (orc.mvn_logp(x, f, var + h, ls, jit) - orc.mvn_logp(x, f, var - h, ls, jit)) / (2 * h)
+        fd_l = (orc.mvn_logp(x, f, var, ls + h, jit) - orc.mvn_logp(x, f, var, ls - h, jit)) / (2 * h)
+        assert abs(gv - fd_v) < 1e-4 * max(1, abs(fd_v)) and abs(gl - fd_l) < 1e-4 * max(1, abs(fd_l))
+        e = np.zeros(n); e[3] = h
+        fd_f = (orc.mvn_logp(x, f + e, var, ls, jit) - orc.mvn_logp(x, f - e, var, ls, jit)) / (2 * h)
+        assert abs(gf[3] - fd_f) < 1e-4 * max(1, abs(fd_f))
