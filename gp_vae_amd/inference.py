@@ -80,6 +80,38 @@ class GPInference(Inference):
         self.last_info = info
         return (mean, sample, var_out) if return_var else (mean, sample)
 
+    def potential_and_grad(self, f, log_var, log_ls, log_sigma):
+        """Potential energy of gp_regression (inference.py:400-424) in NumPyro's unconstrained space
+        and its gradient, for a batch of chains — what NUTS evaluates per leapfrog step.
+
+        sites: kernel_var ~ LogNormal(0,0.1), kernel_sigma ~ HalfNormal(0.1),
+               kernel_length ~ InverseGamma(4,1), f ~ MVN(0, kernel(x_obs, x_obs, var, ls)),
+               y_pred ~ Normal(f, sigma) observed at x_obs.
+        f: [chains, n_obs]; log_var, log_ls, log_sigma: [chains].
+        Returns (U [chains], dU/df [chains, n_obs], dU/dlog_var, dU/dlog_ls, dU/dlog_sigma).
+        The MVN term and its gradient are one gpvae_mvn_logp call; the priors and the Gaussian
+        likelihood are O(chains * n_obs) glue."""
+        x_obs = self.x[self.obs_idx].contiguous()
+        y_obs = self.y[self.obs_idx]
+        n = x_obs.shape[0]
+        f = _as_device(f, self.dtype).reshape(-1, n).contiguous()
+        uv, ul, us = (_as_device(t, self.dtype).reshape(-1) for t in (log_var, log_ls, log_sigma))
+        var, ls, sig = torch.exp(uv), torch.exp(ul), torch.exp(us)
+        lp, gf, gv, gl, info = ops.mvn_logp(x_obs, f, var, ls, 1.0e-5)
+        self.last_info = info
+        s0, hl2p = 0.1, 0.5 * math.log(2 * math.pi)
+        r = (y_obs[None, :] - f) / sig[:, None]
+        sq = (r * r).sum(1)
+        logp = (-math.log(s0) - hl2p - uv ** 2 / (2 * s0 ** 2)) \
+            + (math.log(2.0) - hl2p - math.log(s0) - 0.5 * (sig / s0) ** 2 + us) \
+            + (-math.lgamma(4.0) - 4.0 * ul - 1.0 / ls) \
+            + lp + (-0.5 * sq - n * us - n * hl2p)
+        d_f = gf + r / sig[:, None]
+        d_uv = -uv / s0 ** 2 + gv * var
+        d_ul = -4.0 + 1.0 / ls + gl * ls
+        d_us = 1.0 - (sig / s0) ** 2 + sq - n
+        return -logp, -d_f, -d_uv, -d_ul, -d_us
+
     def gp_fit_from_samples(self, rng_key, post_samples):
         """The posterior-predictive sweep of gp_fit (inference.py:511-521): one gp_prediction per
         posterior draw of (kernel_var, kernel_length, kernel_sigma).  With torch.distributed

@@ -205,6 +205,23 @@ def mvn_logp_grads(x, f, var, ls, jitter=1.0e-5):
     return mvn_logp(x, f, var, ls, jitter), -alpha, float((G * K0).sum() / var), float((G * K0 * D2).sum() / ls ** 3)
 
 
+def gp_regression_potential(x, y, f, u_var, u_ls, u_sig, jitter=1.0e-5):
+    """Potential energy (-log joint in NumPyro's unconstrained space, exp transforms) of
+    GPInference.gp_regression (inference.py:407-424): kernel_var ~ LogNormal(0, 0.1),
+    kernel_sigma ~ HalfNormal(0.1), kernel_length ~ InverseGamma(4, 1), f ~ MVN(0, k),
+    y_pred ~ Normal(f, sigma) observed."""
+    import math
+    var, ls, sig = np.exp(u_var), np.exp(u_ls), np.exp(u_sig)
+    n = len(f)
+    lp = -math.log(0.1 * math.sqrt(2 * math.pi)) - u_var ** 2 / (2 * 0.1 ** 2)            # LogNormal + Jacobian
+    lp += math.log(2.0) - 0.5 * math.log(2 * math.pi) - math.log(0.1) - 0.5 * (sig / 0.1) ** 2 + u_sig  # HalfNormal
+    lp += 4 * math.log(1.0) - math.lgamma(4.0) - 4 * u_ls - 1.0 / ls                         # InverseGamma(4,1)
+    lp += mvn_logp(x, f, var, ls, jitter)
+    r = (np.asarray(y) - np.asarray(f)) / sig
+    lp += float(-0.5 * r @ r - n * u_sig - 0.5 * n * math.log(2 * math.pi))
+    return -lp
+
+
 # --------------------------------------------------------------------------------------------------
 # a5/a6  stax encoder/decoder + Trace_ELBO loss  (src/model/vae.py:72-137, 213-218)
 # --------------------------------------------------------------------------------------------------

@@ -337,6 +337,36 @@ def test_mvn_logp_and_gradient(ops, ndt, tdt, tol):
             assert abs(gv[s].item() - gvo) < t * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < t * max(1.0, abs(glo)), (n, s)
 
 
+def test_gp_regression_potential_gradient(ops, golden):
+    """GPInference.potential_and_grad (what NUTS differentiates in gp_regression) against the oracle's
+    potential and central finite differences of it, fp64."""
+    from gp_vae_amd.gp import exp_kernel2
+    from gp_vae_amd.inference import GPInference
+    rng = np.random.default_rng(12)
+    n = 60
+    x = np.arange(n) / n
+    obs = np.sort(rng.permutation(n)[:25])
+    y = np.full(n, np.nan); y[obs] = np.sin(6 * x[obs]) + 0.05 * rng.standard_normal(25)
+    inf = GPInference(exp_kernel2, 1, x, y, obs, {}, dtype=torch.float64)
+    C = 3
+    uv, ul, us = rng.normal(0, 0.1, C), np.log(rng.uniform(0.15, 0.4, C)), np.log(rng.uniform(0.05, 0.2, C))
+    # latent values drawn from the prior they are scored under (a random f would make f^T K^-1 f ~ 1e6
+    # and the finite differences below meaningless)
+    f = np.stack([np.linalg.cholesky(orc.exp_kernel2(x[obs], x[obs], np.exp(uv[c]), np.exp(ul[c]), 1e-5)) @ rng.standard_normal(25) for c in range(C)])
+    U, dF, dV, dL, dS = inf.potential_and_grad(f, uv, ul, us)
+    h = 1e-5
+    for c in range(C):
+        P = lambda ff, a, b, g: orc.gp_regression_potential(x[obs], y[obs], ff, a, b, g)
+        u0 = P(f[c], uv[c], ul[c], us[c])
+        assert abs(U[c].item() - u0) < 1e-9 * abs(u0)
+        fd = lambda fn: (fn(h) - fn(-h)) / (2 * h)
+        assert abs(dV[c].item() - fd(lambda e: P(f[c], uv[c] + e, ul[c], us[c]))) < 1e-4 * max(1, abs(dV[c].item()))
+        assert abs(dL[c].item() - fd(lambda e: P(f[c], uv[c], ul[c] + e, us[c]))) < 1e-4 * max(1, abs(dL[c].item()))
+        assert abs(dS[c].item() - fd(lambda e: P(f[c], uv[c], ul[c], us[c] + e))) < 1e-4 * max(1, abs(dS[c].item()))
+        e7 = np.zeros(25); e7[7] = 1.0
+        assert abs(dF[c, 7].item() - fd(lambda e: P(f[c] + e * e7, uv[c], ul[c], us[c]))) < 1e-4 * max(1, abs(dF[c, 7].item()))
+
+
 # ---- a5/a6/a7/a11 --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
 def test_vae_elbo_adam_decoder_golden(ops, golden, ndt, tdt, tol):

@@ -145,3 +145,21 @@ if "f2" in which:  # batched small kriging: the reference's vmap over posterior 
                           "problems_per_s": S / t, "ms_total": t * 1e3, "tflops": flop / t / 1e12,
                           "one_at_a_time_problems_per_s": 1 / tl, "cpu_oracle_problems_per_s": 1 / tc,
                           "pd_fraction": float((info == 0).float().mean().item()), "rel_err_vs_oracle_draw9": err}), flush=True)
+
+if "f1" in which:  # gp_regression potential + gradient for a batch of chains
+    from gp_vae_amd.gp import exp_kernel2
+    rng = np.random.default_rng(0)
+    for n_obs, chains in ((100, 1024), (400, 1024)):
+        g = np.arange(25) / 25.0
+        u, v = np.meshgrid(g, g)
+        x = np.stack([u.ravel(), v.ravel()], 1)
+        obs = np.sort(rng.permutation(x.shape[0])[:n_obs])
+        y = np.full(x.shape[0], np.nan); y[obs] = np.sin(4 * x[obs].sum(1))
+        inf = GPInference(exp_kernel2, 2, x, y, obs, {}, dtype=torch.float32)
+        f = torch.tensor(rng.standard_normal((chains, n_obs)) * 0.3, dtype=torch.float32, device=dev)
+        uv = torch.zeros(chains, device=dev); ul = torch.full((chains,), math.log(0.3), device=dev); us = torch.full((chains,), math.log(0.1), device=dev)
+        t = timed(lambda: inf.potential_and_grad(f, uv, ul, us), 5)
+        flop = chains * (n_obs ** 3 / 3 + 2.0 * n_obs ** 3)
+        print(json.dumps({"config": "f1: gp_regression potential+gradient, n_obs=%d, %d chains, f32" % (n_obs, chains),
+                          "grad_evals_per_s": chains / t, "ms_per_batched_eval": t * 1e3, "tflops": flop / t / 1e12,
+                          "pd_fraction": float((inf.last_info == 0).float().mean().item())}), flush=True)
