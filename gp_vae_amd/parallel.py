@@ -22,6 +22,21 @@ def allreduce_sum_(t):
     return t
 
 
+def allreduce_sum_start(t):
+    """Start the in-place SUM over ranks; returns a handle for allreduce_wait (None on one rank).
+    The collective runs on RCCL's own stream once the current stream's work on `t` is done, so
+    kernels enqueued after this call overlap with it."""
+    if dist_info()[1] > 1:
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def allreduce_wait(handle):
+    """The current stream waits for the collective started by allreduce_sum_start."""
+    if handle is not None:
+        handle.wait()
+
+
 def step_rng(seed, rank, key):
     """Host RNG of one (rank, step): ranks draw different (ls, var, sigma), replays are exact."""
     return np.random.default_rng([int(seed), int(rank)] + [int(k) for k in key])

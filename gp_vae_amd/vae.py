@@ -28,7 +28,7 @@ from . import _lib, ops
 from ._lib import GpvaeError, check
 from .ops import _dt, _p, _stream
 from .gp import Predictive, _as_device, _seed_of, draw_hyper
-from .parallel import allreduce_sum_, dist_info, philox_stream_id, step_rng
+from .parallel import allreduce_sum_start, allreduce_wait, allreduce_sum_, dist_info, philox_stream_id, step_rng
 
 
 class SVIState():
@@ -102,8 +102,9 @@ class StepEngine():
         self.pwork = [torch.empty(max(16, wbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.E = torch.empty((B, n), dtype=dtype, device=dev)
         self.E2 = torch.empty((B, n), dtype=dtype, device=dev)
-        self.Y = torch.empty((B, n), dtype=dtype, device=dev)
-        self.eps_z = torch.empty((B, self.z), dtype=dtype, device=dev)
+        # two draw buffers: step t+1 is drawn while step t's gradient all-reduce is in flight
+        self.Ybuf = [torch.empty((B, n), dtype=dtype, device=dev) for _ in range(2)]
+        self.ezbuf = [torch.empty((B, self.z), dtype=dtype, device=dev) for _ in range(2)]
         self.grads = torch.empty(ops.vae_param_count(n, self.h0, self.h1, self.z), dtype=dtype,
                                  device=dev)
         self.loss = torch.zeros(1, dtype=dtype, device=dev)
@@ -145,13 +146,14 @@ class StepEngine():
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
-    def _consume(self, key, slot, i, last_of_group, state, train):
+    def _produce(self, key, slot, i, last_of_group, buf):
+        """Normals and the B draws of one step into draw buffer `buf` (main stream)."""
         main = torch.cuda.current_stream()
         if self.overlap and i == 0:
             main.wait_event(self.ev_ready[slot])
         ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
         ops.randn(None, out=self.E2, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 2))
-        ops.randn(None, out=self.eps_z, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
+        ops.randn(None, out=self.ezbuf[buf], seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
         K = self.Kbuf[slot][i]
         sig = self.hyper_dev[slot][2, i:i + 1]
         lib = _lib.load()
@@ -159,20 +161,27 @@ class StepEngine():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
         check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
-                             _p(self.E2), self.n, _p(sig), None, 0, _p(self.Y), self.n),
+                             _p(self.E2), self.n, _p(sig), None, 0, _p(self.Ybuf[buf]), self.n),
               "gpvae_draw")
         if self.draw_events is not None:
             ev[1].record(main)
             self.draw_events.append(ev)
         if self.overlap and last_of_group:
             self.ev_free[slot].record(main)
-        ops.vae_elbo(state.params, self.Y, self.eps_z, (self.h0, self.h1, self.z), self.obs_sigma,
-                     grads=self.grads if train else None, loss=self.loss, work=self.work)
+
+    def _learn_start(self, buf, state, train):
+        """ELBO (+ gradient) of the step in draw buffer `buf`; starts the one collective of the path
+        (flat-gradient SUM, RCCL over xGMI) and returns its handle."""
+        ops.vae_elbo(state.params, self.Ybuf[buf], self.ezbuf[buf], (self.h0, self.h1, self.z),
+                     self.obs_sigma, grads=self.grads if train else None, loss=self.loss, work=self.work)
+        self.loss_sum += self.loss
+        return allreduce_sum_start(self.grads) if train else None
+
+    def _learn_finish(self, handle, state, train):
         if train:
-            allreduce_sum_(self.grads)  # the one collective of the path (RCCL over xGMI)
+            allreduce_wait(handle)
             state.t += 1
             ops.adam_(state.params, self.grads, state.m, state.v, state.t, self.lr)
-        self.loss_sum += self.loss
 
     def run(self, keys, state, train=True):
         """Run the steps named by `keys` (tuples of ints feeding the per-step RNG streams).
@@ -186,12 +195,23 @@ class StepEngine():
             for s in range(2):
                 self.ev_free[s].record(torch.cuda.current_stream())
         self._issue_factors(groups[0], 0)
+        # software pipeline over steps: draw(t+1) does not depend on the parameters, so it is
+        # enqueued between the start of step t's gradient all-reduce and the Adam step that waits
+        # for it — the collective's latency hides behind the draw.  Same arithmetic in any order.
+        pending = None  # (handle,) of the step whose Adam update is still to come
+        t = 0
         for gi, grp in enumerate(groups):
             slot = gi & 1
             if gi + 1 < len(groups):
                 self._issue_factors(groups[gi + 1], (gi + 1) & 1)
             for i, key in enumerate(grp):
-                self._consume(key, slot, i, i == len(grp) - 1, state, train)
+                self._produce(key, slot, i, i == len(grp) - 1, t & 1)
+                if pending is not None:
+                    self._learn_finish(pending[0], state, train)
+                pending = (self._learn_start(t & 1, state, train),)
+                t += 1
+        if pending is not None:
+            self._learn_finish(pending[0], state, train)
         return self.loss_sum
 
 

@@ -1,5 +1,6 @@
 """GPU tests of the training loop (a8): the stream-overlapped StepEngine reproduces the oracle's
 train_step on identical inputs, and the reference-surface VAE.fit trains (C1 plumbing config)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -78,3 +79,57 @@ def test_vae_fit_reference_surface_trains():
     out2 = pred(5, x=x, ls=0.05, var=1.0, sigma=0.01)
     assert out2["y"].shape == (12, n) and "length" not in out2
     assert (out2["y"] - out2["f"]).std().item() < 0.02
+
+
+def _engine_rank_worker(rank, world, port, tmp):
+    """One rank of a 2-rank StepEngine run; both ranks share cuda:0, the collective goes through gloo
+    (the RCCL path needs one GPU per rank; the driver exercises it with bench.py --gpus N)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gp_vae_amd.vae import StepEngine, SVIState, init_params
+        n, B, dims = 96, 40, (12, 9, 4)
+        x = np.arange(0, 1, 1 / n)
+        eng = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float64, seed=3, group=2)
+        st = SVIState(init_params(n, *dims, 7, torch.float64, DEV) * 5)
+        loss = eng.run([(2, i) for i in range(5)], st, train=True)
+        np.savez(os.path.join(tmp, "eng%d.npz" % rank), params=st.params.cpu().numpy(), loss=loss.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_engine_two_ranks_pipelined_allreduce(tmp_path):
+    """The pipelined step loop (all-reduce of step t in flight while step t+1 is drawn) on two ranks
+    equals a single-process emulation that computes both ranks' gradients one after the other, sums
+    them and applies one Adam step — and both replicas end identical."""
+    import torch.multiprocessing as mp
+    from gp_vae_amd import ops
+    from gp_vae_amd.vae import StepEngine, SVIState, init_params
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_engine_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "eng0.npz"), np.load(tmp_path / "eng1.npz")
+    assert np.array_equal(r0["params"], r1["params"])
+    n, B, dims = 96, 40, (12, 9, 4)
+    x = np.arange(0, 1, 1 / n)
+    engs = []
+    for r in range(2):
+        e = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float64, seed=3, group=1, overlap=False)
+        e.rank = r  # this engine draws rank r's hyper-parameters and normals
+        engs.append(e)
+    st = SVIState(init_params(n, *dims, 7, torch.float64, DEV) * 5)
+    losses = [0.0, 0.0]
+    for i in range(5):
+        g = None
+        for r, e in enumerate(engs):
+            e._issue_factors([(2, i)], 0)
+            e._produce((2, i), 0, 0, True, 0)
+            ops.vae_elbo(st.params, e.Ybuf[0], e.ezbuf[0], dims, e.obs_sigma, grads=e.grads, loss=e.loss, work=e.work)
+            losses[r] += e.loss.item()
+            g = e.grads.clone() if g is None else g + e.grads
+        st.t += 1
+        ops.adam_(st.params, g, st.m, st.v, st.t, 1e-3)
+    assert rel(r0["params"], st.params.cpu().numpy()) < 1e-9
+    assert abs(float(r0["loss"][0]) - losses[0]) < 1e-9 * abs(losses[0])
+    assert abs(float(r1["loss"][0]) - losses[1]) < 1e-9 * abs(losses[1])
