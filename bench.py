@@ -52,7 +52,7 @@ def bench_hyper(rng):
     return min(max(float(ls), 0.05), 1.0), float(var), float(sigma)
 
 
-def cpu_baseline(steps=3):
+def cpu_baseline(steps=12, budget_s=12.0):
     """The oracle's train_step (NumPy/SciPy, multi-threaded LAPACK) at the same sizes."""
     from oracle import gpvae_oracle as orc
     try:
@@ -76,7 +76,7 @@ def cpu_baseline(steps=3):
         _, p, m, v = orc.train_step(p, m, v, t, x, hyper, E, E2, ez, LR, JITTER)
         t_used += time.perf_counter() - t0
         done += 1
-        if t_used > 25.0:
+        if t_used > budget_s:  # a bounded sample: about 10-15 s of CPU work
             break
     return {"value": B * done / t_used, "unit": "draws/s", "cores": int(cores), "kind": "port",
             "sample": "%d full training steps (n=4096, B=4096, f32) of oracle.train_step, "
