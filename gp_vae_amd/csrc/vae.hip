@@ -238,6 +238,7 @@ __device__ __forceinline__ void dense_fwd(const T *in, int K, const T *__restric
   for (int idx = tid; idx < RB * N; idx += NTHREADS) {
     const int r = idx / N, j = idx % N;
     T a = bias[j];
+#pragma unroll 8
     for (int k = 0; k < K; ++k) a += in[r * K + k] * W[(int64_t)k * N + j];
     out[r * N + j] = a;
   }
@@ -249,6 +250,7 @@ __device__ __forceinline__ void dense_bwd_in(const T *d, int N, const T *__restr
   for (int idx = tid; idx < RB * K; idx += NTHREADS) {
     const int r = idx / K, k = idx % K;
     T a = accumulate ? out[r * K + k] : T(0);
+#pragma unroll 8
     for (int j = 0; j < N; ++j) a += d[r * N + j] * W[(int64_t)k * N + j];
     out[r * K + k] = a;
   }
@@ -261,6 +263,7 @@ __device__ __forceinline__ void dense_bwd_w(const T *in, int K, const T *d, int 
     const int k = idx / N, j = idx % N;
     T a = T(0);
     if (k < K) {
+#pragma unroll 8
       for (int r = 0; r < rows; ++r) a += in[r * K + k] * d[r * N + j];
       atomicAdd(&dW[(int64_t)k * N + j], a);
     } else {
@@ -287,7 +290,32 @@ template <typename T> struct VaeParams {
     V2 = c1 + h1;      c2 = V2 + (int64_t)h1 * h0;
     V3 = c2 + h0;      c3 = V3 + (int64_t)h0 * n;
   }
+  // the contiguous run b1 .. c2 (everything but the two n-sized layers) relocated to `mid`
+  // (an LDS copy): elements [n*h0, n*h0 + mid_count) of the flat vector
+  __host__ __device__ static int64_t mid_count(int h0, int h1, int z) {
+    return h0 + (int64_t)h0 * h1 + h1 + 2 * ((int64_t)h1 * z + z) + (int64_t)z * h1 + h1 +
+           (int64_t)h1 * h0 + h0;
+  }
+  __device__ void relocate_mid(const T *mid, int h0, int h1, int z) {
+    b1 = mid;
+    W2 = b1 + h0;      b2 = W2 + h0 * h1;
+    Wmu = b2 + h1;     bmu = Wmu + h1 * z;
+    Wsd = bmu + z;     bsd = Wsd + h1 * z;
+    V1 = bsd + z;      c1 = V1 + z * h1;
+    V2 = c1 + h1;      c2 = V2 + h1 * h0;
+  }
 };
+// Copies the mid-layer weights (b1 .. c2, a few thousand elements) into LDS once per workgroup: the
+// per-sample dense layers then read weights at LDS latency instead of one L2 round trip per k.
+template <typename T>
+__device__ __forceinline__ void stage_mid(VaeParams<T> &P, const T *params, T *wl, int64_t n, int h0,
+                                          int h1, int z, int tid) {
+  const int64_t cnt = VaeParams<T>::mid_count(h0, h1, z);
+  const T *src = params + n * h0;
+  for (int64_t i = tid; i < cnt; i += NTHREADS) wl[i] = src[i];
+  P.relocate_mid(wl, h0, h1, z);
+  __syncthreads();
+}
 static inline int64_t vae_param_count(int64_t n, int h0, int h1, int z) {
   return n * h0 + h0 + (int64_t)h0 * h1 + h1 + 2 * ((int64_t)h1 * z + z) + (int64_t)z * h1 + h1 +
          (int64_t)h1 * h0 + h0 + (int64_t)h0 * n + n;
@@ -313,18 +341,19 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, const T *params,
                                                                const T *eps, T *H1, T *H2, T *SD,
                                                                T *Z, T *D1, T *D2, T *loss,
-                                                               T loss_const) {
+                                                               T loss_const, int stage) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *bufA = reinterpret_cast<T *>(smem_raw);  // [RB][max dim]
   const int mx = max(d.h0, max(d.h1, d.z));
   T *bufB = bufA + RB * mx;
   T *bufC = bufB + RB * mx;
   __shared__ T red[4];
-  const VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
+  VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
   const int tid = threadIdx.x;
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
   const int h0 = d.h0, h1 = d.h1, z = d.z;
+  if (stage) stage_mid<T>(P, params, bufC + RB * mx, d.n, h0, h1, z, tid);
 
   // H1 = relu(A1 + b1)
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
@@ -399,19 +428,20 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
                                                                const T *H1, const T *H2,
                                                                const T *SD, const T *Z,
                                                                const T *D1, const T *D2,
-                                                               const T *dD2, T *dA1) {
+                                                               const T *dD2, T *dA1, int stage) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int mx = max(d.h0, max(d.h1, d.z));
   T *act = reinterpret_cast<T *>(smem_raw);  // activations of the layer input
   T *gA = act + RB * mx;                     // gradient buffers
   T *gB = gA + RB * mx;
   T *gC = gB + RB * mx;
-  const VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
+  VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
   const VaeParams<T> G(grads, d.n, d.h0, d.h1, d.z);  // same layout; const-cast below
   const int tid = threadIdx.x;
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
   const int h0 = d.h0, h1 = d.h1, z = d.z;
+  if (stage) stage_mid<T>(P, params, gC + RB * mx, d.n, h0, h1, z, tid);
   auto ld = [&](const T *src, int64_t r, int w, int j) { return r < rows ? src[(s0 + r) * w + j] : T(0); };
 
   // dG2 = dD2 * (D2 > 0);  act = D1
@@ -562,7 +592,11 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   VaeParams<T> P(params, n, h0, h1, z);
   VaeDims<T> dims{B, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
-  const size_t shm_f = 3 * (size_t)RB * mx * sizeof(T), shm_b = 4 * (size_t)RB * mx * sizeof(T);
+  // the mid-layer weights are staged in LDS when they fit beside the activation buffers
+  const size_t mid_bytes = (size_t)VaeParams<T>::mid_count(h0, h1, z) * sizeof(T);
+  const int stage = mid_bytes + 4 * (size_t)RB * mx * sizeof(T) <= 60 * 1024;  // default dynamic-LDS limit
+  const size_t shm_f = 3 * (size_t)RB * mx * sizeof(T) + (stage ? mid_bytes : 0);
+  const size_t shm_b = 4 * (size_t)RB * mx * sizeof(T) + (stage ? mid_bytes : 0);
   const unsigned nblk = (unsigned)cdiv(B, RB);
   const T inv_var = (T)(1.0 / (obs_sigma * obs_sigma));
   // constant of the data term: B*n*(log sigma + 0.5 log 2pi)
@@ -578,7 +612,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
     launch_gemm<T, true, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
   }
   hipLaunchKernelGGL((vae_mid_fwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_f, st, dims, params,
-                     eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss, loss_const);
+                     eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss, loss_const, stage);
   {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
     GemmArgs<T> g{};
     g.A = W.D2; g.lda = h0; g.B = P.V3; g.ldb = n; g.C = W.DF; g.ldc = n;
@@ -606,7 +640,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
       launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
     }
     hipLaunchKernelGGL((vae_mid_bwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_b, st, dims,
-                       params, grads, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, W.dD2, W.dA1);
+                       params, grads, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, W.dD2, W.dA1, stage);
     {  // [dW1; db1] += [Y | 1]^T dA1        ((n+1) x h0; W1 and b1 are adjacent in the layout)
       GemmArgs<T> g{};
       g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = (T *)G.W1; g.ldc = h0;
