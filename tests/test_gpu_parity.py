@@ -331,8 +331,10 @@ def test_mvn_logp_and_gradient(ops, ndt, tdt, tol):
         assert info[2] > 0 and np.isnan(lp[2].item()) and np.isnan(gv[2].item())
         for s in (0, 1, 3):
             lo, gfo, gvo, glo = orc.mvn_logp_grads(x, F[s], var[s], ls[s], jit)
-            t = 1e-7 if ndt == np.float64 else 2e-2
-            assert abs(lp[s].item() - lo) < t * abs(lo), (n, s)
+            # fp32: cond(K) ~ 1e5 at these sizes, so gradients carry ~cond * 6e-8 (measured <= 7e-3);
+            # the value itself is good to 3e-5
+            t = 1e-7 if ndt == np.float64 else 1e-2
+            assert abs(lp[s].item() - lo) < (1e-7 if ndt == np.float64 else 1e-3) * abs(lo), (n, s)
             assert rel(gf[s], gfo) < t, (n, s)
             assert abs(gv[s].item() - gvo) < t * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < t * max(1.0, abs(glo)), (n, s)
 
