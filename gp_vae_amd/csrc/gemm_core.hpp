@@ -621,13 +621,27 @@ struct PipeKC {
     const int nplain = (kfast > kbeg) ? (int)((kfast - kbeg) / BK) : 0;
     const int npairs = (nplain >= 4) ? (nplain - 2) / 2 : 0;
 
-    la.load(kbeg, kend, tid);
-    lb.load(kbeg, kend, tid);
-    la.template store<LD>(lds, tid);
-    lb.template store<LD>(lds + RA * LD, tid);
+    // tiles 0 and 1: through the fast path too when they are plain (keeps the prologue, which may
+    // run next to another block's MFMA stream, almost free of vector-ALU work)
+    if (nplain >= 1) {
+      la.load_fast(kbeg, kend);
+      lb.load_fast(kbeg, kend);
+      la.template store_fast<LD>(lds, tid);
+      lb.template store_fast<LD>(lds + RA * LD, tid);
+    } else {
+      la.load(kbeg, kend, tid);
+      lb.load(kbeg, kend, tid);
+      la.template store<LD>(lds, tid);
+      lb.template store<LD>(lds + RA * LD, tid);
+    }
     if (kbeg + BK < kend) {
-      la.load(kbeg + BK, kend, tid);
-      lb.load(kbeg + BK, kend, tid);
+      if (nplain >= 2) {
+        la.load_fast(kbeg + BK, kend);
+        lb.load_fast(kbeg + BK, kend);
+      } else {
+        la.load(kbeg + BK, kend, tid);
+        lb.load(kbeg + BK, kend, tid);
+      }
     }
     __syncthreads();
     if (compute) read_half<0, 0>(lds, aoff, boff);

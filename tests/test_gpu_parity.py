@@ -331,9 +331,10 @@ def test_mvn_logp_and_gradient(ops, ndt, tdt, tol):
         assert info[2] > 0 and np.isnan(lp[2].item()) and np.isnan(gv[2].item())
         for s in (0, 1, 3):
             lo, gfo, gvo, glo = orc.mvn_logp_grads(x, F[s], var[s], ls[s], jit)
-            # fp32: cond(K) ~ 1e5 at these sizes, so gradients carry ~cond * 6e-8 (measured <= 7e-3);
-            # the value itself is good to 3e-5
-            t = 1e-7 if ndt == np.float64 else 1e-2
+            # fp32: cond(K) ~ 1e5 at these sizes; d/dvar and d/dls are differences of two O(n) terms
+            # (alpha^T dK alpha and tr(K^-1 dK)), each good to ~1e-4 relative, so the bound scales
+            # with n; the value itself is good to 3e-5
+            t = 1e-7 if ndt == np.float64 else max(1e-2, 1e-4 * n)
             assert abs(lp[s].item() - lo) < (1e-7 if ndt == np.float64 else 1e-3) * abs(lo), (n, s)
             assert rel(gf[s], gfo) < t, (n, s)
             assert abs(gv[s].item() - gvo) < t * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < t * max(1.0, abs(glo)), (n, s)
