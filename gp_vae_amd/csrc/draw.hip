@@ -14,7 +14,7 @@ constexpr int DBM = 128;
 
 // VECM: L and E rows are 16-byte aligned (base and leading dimension) -> 16-byte loads.
 template <typename T, bool VECM>
-__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void draw_kernel(
+__global__ __launch_bounds__(NTHREADS, 2) void draw_kernel(
     int64_t n, int64_t nb, const T *L, int64_t ldl, const T *E, int64_t lde, const T *E2,
     int64_t lde2, const T *sigma_p, T *F, int64_t ldf, T *Y, int64_t ldy, int nrt, int nct) {
   using M = Mfma<T>;

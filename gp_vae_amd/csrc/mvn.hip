@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, 
 
 // tiles of K^-1 = U U^T against K0 and K0 r^2.  grid (tiles, tiles, batch)
 template <typename T, int D, bool VECM>
-__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void mvn_grad_kernel(
+__global__ __launch_bounds__(NTHREADS, 2) void mvn_grad_kernel(
     int64_t n, const T *X, int64_t ldx, int64_t strideX, const T *x, const T *var_p, const T *ls_p,
     const T *alpha, T *acc2) {
   using M = Mfma<T>;

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 constexpr int SBM = 128;
 
 template <typename T, bool VECM>
-__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 2 : 1) void potrf_syrk_kernel(
+__global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
     VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cJ, int64_t kend) {
   using M = Mfma<T>;
   constexpr int SBK = TileK<T>::BK;
