@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .hmc import hmc
 from ._lib import GpvaeError
 from .gp import _as_device, _seed_of, exp_kernel2
 from .parallel import shard
@@ -45,9 +46,26 @@ class Inference():
     def regression(self, y=None, obs_idx=None):
         raise NotImplementedError  # inference.py:63-66
 
+    def _mcmc(self, rng_key, potential, q0):
+        """mcmc_args of the reference (num_warmup, num_samples, num_chains, thinning;
+        inference.py:86-93) driving the batched HMC of gp_vae_amd.hmc (NUTS is third-party code
+        that is absent here — same target, different trajectory rule).  q0: [dim] start, jittered
+        per chain.  Returns samples [num_samples // thinning * num_chains, dim] (chains
+        concatenated, as mcmc.get_samples() does) and the sampler's info dict."""
+        a = self.mcmc_args
+        chains = int(a.get("num_chains", 1))
+        gen = torch.Generator(device=q0.device)
+        gen.manual_seed(_seed_of(rng_key))
+        start = q0[None, :] + 0.01 * torch.randn((chains, q0.numel()), dtype=q0.dtype, device=q0.device,
+                                                  generator=gen)
+        smp, info = hmc(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
+                        thinning=int(a.get("thinning", 1)), num_leapfrog=int(a.get("num_leapfrog", 16)),
+                        seed=_seed_of(rng_key) + 1)
+        self.mcmc_info = info
+        return smp.permute(1, 0, 2).reshape(-1, q0.numel()), info
+
     def run_mcmc(self, rng_key):
-        raise GpvaeError("run_mcmc drives numpyro.infer.NUTS, which is third-party code absent from "
-                         "this environment; use potential_and_grad / gp_prediction with your sampler")
+        raise NotImplementedError  # the subclasses know their model (inference.py:69-99)
 
 
 class GPInference(Inference):
@@ -112,6 +130,31 @@ class GPInference(Inference):
         d_us = 1.0 - (sig / s0) ** 2 + sq - n
         return -logp, -d_f, -d_uv, -d_ul, -d_us
 
+    def gp_run_mcmc(self, rng_key):
+        """Posterior samples of gp_regression at the observed points (inference.py:463-490):
+        dict with kernel_var, kernel_sigma, kernel_length [S] and f [S, n_obs]."""
+        n = int(self.obs_idx.numel())
+        # init_to_median of the priors: var 1, ls median of InverseGamma(4,1), sigma median of HalfNormal(.1)
+        q0 = torch.zeros(n + 3, dtype=self.dtype, device=self.x.device)
+        q0[n + 1] = math.log(0.2723)
+        q0[n + 2] = math.log(0.0674)
+
+        def potential(q):
+            U, dF, dV, dL, dS = self.potential_and_grad(q[:, :n], q[:, n], q[:, n + 1], q[:, n + 2])
+            return U, torch.cat([dF, dV[:, None], dL[:, None], dS[:, None]], 1)
+
+        smp, _ = self._mcmc(rng_key, potential, q0)
+        return {"f": smp[:, :n], "kernel_var": torch.exp(smp[:, n]), "kernel_length": torch.exp(smp[:, n + 1]),
+                "kernel_sigma": torch.exp(smp[:, n + 2])}
+
+    def gp_fit(self, plot=False, rng_key=None):
+        """MCMC over the GP hyper-parameters, then kriging per posterior draw (inference.py:493-549).
+        Returns (means, predictions), each [S, n_test].  Plotting is out of scope."""
+        key = _seed_of(self.seed if rng_key is None else rng_key)
+        post = self.gp_run_mcmc(key + 2)
+        cpu = {k: v.detach().cpu().numpy() for k, v in post.items() if k != "f"}
+        return self.gp_fit_from_samples(key + 3, cpu)
+
     def gp_fit_from_samples(self, rng_key, post_samples):
         """The posterior-predictive sweep of gp_fit (inference.py:511-521): one gp_prediction per
         posterior draw of (kernel_var, kernel_length, kernel_sigma).  With torch.distributed
@@ -156,6 +199,35 @@ class VAEInference(Inference):
         (V1, _), _, (V2, _), _, (V3, _) = decoder_params
         self.h1, self.h0, self.n_out = V1.shape[1], V2.shape[1], V3.shape[1]
         self.dec_flat = decoder_flat_from_list(decoder_params, self.dtype)
+
+    def run_mcmc(self, rng_key):
+        """Posterior samples of VAEInference.regression (inference.py:69-99, 243-254): dict with
+        noise [S], z [S, z_dim] and the deterministic f [S, n] = decoder(z)."""
+        zd = self.z_dim
+        q0 = torch.zeros(zd + 1, dtype=self.dtype, device=self.x.device)
+        q0[zd] = math.log(0.0674)  # median of HalfNormal(0.1)
+
+        def potential(q):
+            U, dz, du = self.potential_and_grad(q[:, :zd], q[:, zd])
+            return U, torch.cat([dz, du[:, None]], 1)
+
+        smp, _ = self._mcmc(rng_key, potential, q0)
+        z = smp[:, :zd].contiguous()
+        return {"z": z, "noise": torch.exp(smp[:, zd]), "f": self.predict(z)}
+
+    def fit(self, plot=False, rng_key=None, num_prior=1000):
+        """Prior and posterior predictive draws y_pred ~ Normal(decoder(z), noise)
+        (inference.py:101-146).  Returns (prior_predictions [num_prior, n], predictions [S, n])."""
+        key = _seed_of(self.seed if rng_key is None else rng_key)
+        dev, dt = self.x.device, self.dtype
+        zp = ops.randn((num_prior, self.z_dim), dt, dev, seed=key, stream_id=0xF17)
+        sp = 0.1 * ops.randn((num_prior,), dt, dev, seed=key, stream_id=0xF18).abs()  # HalfNormal(0.1)
+        fp = self.predict(zp)
+        prior = fp + sp[:, None] * ops.randn(tuple(fp.shape), dt, dev, seed=key, stream_id=0xF19)
+        post = self.run_mcmc(key + 2)
+        f = post["f"]
+        pred = f + post["noise"][:, None] * ops.randn(tuple(f.shape), dt, dev, seed=key + 3, stream_id=0xF1A)
+        return prior, pred
 
     def predict(self, z):
         """f = decoder(decoder_params, z) for a batch of latent vectors [chains, z_dim]."""
