@@ -84,6 +84,27 @@ template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
   return r;
 }
 
+// Pivot scaling with LAPACK-grade rounding.  Every entry of a column of L is scaled by the same
+// 1/L_jj, so an error in it is SYSTEMATIC: on a nearly rank-one matrix (long lengthscale,
+// K ~ var 11^T + jitter I) a 1-ulp bias in 1/sqrt(piv) perturbs the Schur complement by
+// 2 ulp * var * n in norm — at n = 300, jitter 1e-4, f32 that ate the whole margin and reported
+// "not positive definite" where LAPACK's spotrf succeeds.  Hence: L_jj = correctly rounded
+// sqrt(piv) (Newton on the v_rsq seed, Markstein correction), rd = its refined reciprocal, and
+// entries = correctly rounded s / L_jj (one fma correction of s * rd).
+// piv <= 0, NaN or 0 still poison the column (NaN / inf), as wanted.
+template <typename T> __device__ __forceinline__ void pivot_scale(T piv, T &ljj, T &rd) {
+  T y = fast_rsqrt<T>(piv);
+  const T e = fma(-(piv * y), y, T(1));
+  y = fma(T(0.5) * y, e, y);                 // 1/sqrt(piv), refined
+  const T l0 = piv * y;
+  ljj = fma(fma(-l0, l0, piv), T(0.5) * y, l0);  // sqrt(piv), correctly rounded
+  rd = fma(fma(-ljj, y, T(1)), y, y);        // 1/ljj
+}
+template <typename T> __device__ __forceinline__ T div_scaled(T s, T ljj, T rd) {
+  const T q = s * rd;
+  return fma(fma(-q, ljj, s), rd, q);  // s / ljj, correctly rounded (one correction step)
+}
+
 // ---- blocked (16-column windows) lane = row sweeps ---------------------------------------------------
 // A 64-step sweep costs 2016 dependent FMAs per lane.  Split into four 16-column windows it costs
 // 4 x 120, and the contribution of a finished window to the columns right of it is applied with
@@ -121,9 +142,10 @@ __device__ __forceinline__ int sweep16(T (&x)[16], T *Lrow, T *rdiag, int W, int
       const T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       const T piv = lane_bcast<T>(s, c);
       if (!(piv > T(0)) && fail < 0) fail = c;
-      const T rd = fast_rsqrt<T>(piv);
-      T v = (lane > c) ? s * rd : T(0);
-      if (lane == c) v = piv * rd;
+      T ljj, rd;
+      pivot_scale<T>(piv, ljj, rd);
+      T v = (lane > c) ? div_scaled<T>(s, ljj, rd) : T(0);
+      if (lane == c) v = ljj;
       x[j] = v;
       Lrow[lane * S + c] = v;
       if (lane == 0) rdiag[c] = rd;
@@ -146,7 +168,7 @@ __device__ __forceinline__ int sweep16(T (&x)[16], T *Lrow, T *rdiag, int W, int
         for (int e = 0; e < VEC; ++e)
           if (k + e < j) acc[(k + e) & 3] -= x[k + e] * tp[e];
       }
-      x[j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[c + zoff];
+      x[j] = div_scaled<T>((acc[0] + acc[1]) + (acc[2] + acc[3]), Lrow[c * S + c + zoff], rdiag[c + zoff]);
     }
   }
   return fail;
@@ -320,10 +342,27 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 
   // ---- (a) apply columns [cJ, c0) of the outer block: [D; C] -= [Pd; Pc] Pd^T ------------------
   if (c0 > cJ) {
+    // The accumulators START from the (negated) block and the products are added to them:
+    // acc = -C + sum_k P P^T, stored back negated.  Summing the products first and subtracting the
+    // sum from C afterwards loses the small terms against the large first one on nearly rank-one
+    // matrices (long lengthscales): measured 30x LAPACK's backward error and spurious "not positive
+    // definite" reports at n = 300, jitter 1e-4.
     typename M::acc_t accC[FM][FN];
     typename M::acc_t accD[1][DN];
-    zero_acc<T, FM, FN>(accC);
-    zero_acc<T, 1, DN>(accD);
+    __syncthreads();  // the copy-in above is complete
+#pragma unroll
+    for (int fn = 0; fn < DN; ++fn)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r)
+        accD[0][fn][r] = -Dm[(dm0 + M::row(lane, r)) * S + dn0 + fn * M::TM + M::col(lane)];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int ci = wave * RPW + fm * M::TM + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) accC[fm][fn][r] = -Cw[ci * S + fn * M::TM + M::col(lane)];
+      }
     LoaderKC<T, SROWS, PBK, VECM> ld;
     ld.init(
         [&](int s, int64_t &rg) -> const T * {
@@ -343,13 +382,13 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
           mma_ktile<T, 1, DN, PBK, true, LDT, true, LDT>(stage, stage, dm0, dn0, lane, accD);
         });
     STAMP(1);
-    // subtract the products from the LDS image; every element belongs to exactly one lane
+    // back into the LDS image; every element belongs to exactly one lane
 #pragma unroll
     for (int fn = 0; fn < DN; ++fn)
 #pragma unroll
       for (int r = 0; r < M::NACC; ++r) {
         const int i = dm0 + M::row(lane, r), j = dn0 + fn * M::TM + M::col(lane);
-        Dm[i * S + j] -= accD[0][fn][r];
+        Dm[i * S + j] = -accD[0][fn][r];
       }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
       for (int r = 0; r < M::NACC; ++r) {
         const int ci = wave * RPW + fm * M::TM + M::row(lane, r);
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) Cw[ci * S + fn * M::TM + M::col(lane)] -= accC[fm][fn][r];
+        for (int fn = 0; fn < FN; ++fn) Cw[ci * S + fn * M::TM + M::col(lane)] = -accC[fm][fn][r];
       }
   }
   __syncthreads();
