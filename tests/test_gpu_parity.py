@@ -176,6 +176,30 @@ def test_potrf_more_workgroups_than_cus(ops):
     assert err.max().item() < 2e-6, err.max().item()
 
 
+def test_potrf_near_rank_one(ops):
+    """Long lengthscales (the heavy tail of the training prior InverseGamma(1, .1), vae.py:157) make
+    K ~ var 11^T + jitter I.  fp32 LAPACK factors these; so must the HIP path, with a backward error
+    of the same size (regression: summing the panel products before subtracting them, and a 1-ulp
+    biased 1/sqrt(pivot), gave 30x LAPACK's error and spurious info > 0 at C1)."""
+    n = 300
+    x = (np.arange(n) / n).astype(np.float32)
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(24):
+        ls, var = float(10 ** rng.uniform(1, 5)), float(rng.lognormal(0, 0.1))
+        K = ops.gram_se(dev(x, torch.float32), dev(x, torch.float32), var, ls, 1e-4)
+        Kc = K.cpu().numpy()
+        A = K.clone()
+        info = ops.potrf_(A)
+        Ll = np.linalg.cholesky(Kc)  # LAPACK spotrf succeeds on every one of these
+        assert int(info.item()) == 0, (ls, var)
+        L = A.cpu().numpy().astype(np.float64)
+        e_gpu = np.abs(L @ L.T - Kc).max()
+        e_lap = np.abs(Ll.astype(np.float64) @ Ll.astype(np.float64).T - Kc).max()
+        worst = max(worst, e_gpu / e_lap)
+    assert worst < 3.0, worst
+
+
 def test_potrf_full_size_backward_error(ops):
     x = dev(grid2(64), torch.float32)  # C3 size, script jitter (2d_examples.py:503)
     ls = torch.tensor([0.05, 0.3, 1.0], device=DEV)

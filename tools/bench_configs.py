@@ -25,11 +25,7 @@ def timed(f, reps):
 if "c2" in which:  # 1D grid n=1024, B=4096, reference MLP (35,30,10), fp32, jitter 1e-4
     n, B, dims = 1024, 4096, (35, 30, 10)
     x = torch.arange(n, dtype=torch.float32, device=dev) / n
-    def hyper(rng):  # vae.py:157-159 priors, ls clipped as in bench.py (heavy InverseGamma tail)
-        from gp_vae_amd.gp import draw_hyper
-        ls, var, sig = draw_hyper(rng)
-        return min(max(ls, 0.05), 1.0), var, sig
-    eng = StepEngine(x, 1e-4, dims, B, 1e-3, dtype=torch.float32, seed=1, hyper_sampler=hyper, group=16)
+    eng = StepEngine(x, 1e-4, dims, B, 1e-3, dtype=torch.float32, seed=1, group=16)  # priors of vae.py:157-159
     st = SVIState(init_params(n, *dims, 1, torch.float32, dev))
     eng.run([(0, i) for i in range(16)], st, train=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
