@@ -27,7 +27,7 @@
 namespace gpvae {
 
 // ---- generic tile product C (M x N) = A (M x K) B (K x N), 128 x 64 tiles, split K -------------------
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_BIAS = 2, EPI_DF = 3 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_BIAS = 2, EPI_DF = 3, EPI_FUSED = 4 };
 
 template <typename T> struct GemmArgs {
   const T *A;
@@ -47,6 +47,11 @@ template <typename T> struct GemmArgs {
   T *loss;              // EPI_DF: += 0.5 * sum diff^2 * inv_var
   int vec_a, vec_b;
   int trans_c;          // store C transposed: C[col * ldc + row] (EPI_STORE / EPI_ATOMIC)
+  // EPI_FUSED (the dense layers of the wide-MLP path): C = mask(relu([C +] A B [+ bias]));
+  // mask may alias C (each element is read before it is written, by the same lane)
+  int addc, relu;
+  const T *mask;        // keep where mask > 0, else 0 (nullptr: keep all)
+  int64_t ldm;
 };
 
 constexpr int GBM = 128, GBN = 64;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
 
   T lsum = T(0);
   // whole tile inside C: element addresses split into a per-lane and a scalar part (TileIO)
-  const bool interior = EPI != EPI_ATOMIC && !g.trans_c && m0 + GBM <= Mrows && n0 + GBN <= g.N &&
+  const bool interior = EPI != EPI_ATOMIC && EPI != EPI_FUSED && !g.trans_c && m0 + GBM <= Mrows && n0 + GBN <= g.N &&
                         TileIO<T>::usable(g.ldc, 32) && (EPI != EPI_DF || TileIO<T>::usable(g.ldy, 32));
   if (interior) {
     TileIO<T> ioc, ioy;
@@ -189,6 +194,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
           if (in) atomicAdd(&g.C[ci], v);
         } else if constexpr (EPI == EPI_BIAS) {
           if (in) g.C[row * g.ldc + col] = v + g.bias[col];
+        } else if constexpr (EPI == EPI_FUSED) {
+          if (in) {
+            T o = v;
+            if (g.addc) o += g.C[ci];
+            if (g.bias != nullptr) o += g.bias[col];
+            if (g.relu) o = o > T(0) ? o : T(0);
+            if (g.mask != nullptr) o = g.mask[row * g.ldm + col] > T(0) ? o : T(0);
+            g.C[ci] = o;
+          }
         } else {
           const T y = g.Yref[in ? row * g.ldy + col : 0];
           const T b = g.bias[in ? col : 0];
@@ -229,10 +243,11 @@ template <typename T> static inline bool mc_vec_ok(const void *base, int64_t ld)
 }
 
 // ---- per-sample-block dense layers on the vector ALU ----------------------------------------------
-constexpr int RB = 16;  // samples per workgroup in the mid kernels
+// RB = samples per workgroup in the mid kernels (a template parameter: 16 while the activation
+// buffers fit the 64 KB dynamic-LDS default, 4 or 2 for wide hidden layers; pick_rb below)
 
 // out[r][j] = bias[j] + sum_k in[r][k] W[k*N + j]   (r < RB); in/out are LDS, W/bias global
-template <typename T>
+template <typename T, int RB>
 __device__ __forceinline__ void dense_fwd(const T *in, int K, const T *__restrict__ W,
                                           const T *__restrict__ bias, int N, T *out, int tid) {
   for (int idx = tid; idx < RB * N; idx += NTHREADS) {
@@ -244,7 +259,7 @@ __device__ __forceinline__ void dense_fwd(const T *in, int K, const T *__restric
   }
 }
 // out[r][k] = sum_j d[r][j] W[k*N + j]   (input gradient of a dense layer)
-template <typename T>
+template <typename T, int RB>
 __device__ __forceinline__ void dense_bwd_in(const T *d, int N, const T *__restrict__ W, int K,
                                              T *out, int tid, bool accumulate = false) {
   for (int idx = tid; idx < RB * K; idx += NTHREADS) {
@@ -256,7 +271,7 @@ __device__ __forceinline__ void dense_bwd_in(const T *d, int N, const T *__restr
   }
 }
 // dW[k*N + j] += sum_r in[r][k] d[r][j];  db[j] += sum_r d[r][j]   (atomics across workgroups)
-template <typename T>
+template <typename T, int RB>
 __device__ __forceinline__ void dense_bwd_w(const T *in, int K, const T *d, int N, T *dW, T *db,
                                             int rows, int tid) {
   for (int idx = tid; idx < (K + 1) * N; idx += NTHREADS) {
@@ -323,25 +338,26 @@ static inline int64_t vae_param_count(int64_t n, int h0, int h1, int z) {
 
 // workspace carve-up (elements of T)
 template <typename T> struct VaeWork {
-  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *DF;
+  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *MU, *LS, *DF;
   static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
-    return B * (3 * (int64_t)h0 + 2 * (int64_t)h1 + 2 * (int64_t)z + h0) + B * n + 64;
+    return B * (4 * (int64_t)h0 + 2 * (int64_t)h1 + 4 * (int64_t)z) + B * n + 64;
   }
   __host__ VaeWork(T *w, int64_t B, int64_t n, int h0, int h1, int z) {
     H1 = w;            H2 = H1 + B * h0;   SD = H2 + B * h1;   Z = SD + B * z;
     D1 = Z + B * z;    D2 = D1 + B * h1;   dD2 = D2 + B * h0;  dA1 = dD2 + B * h0;
-    DF = dA1 + B * h0;
+    MU = dA1 + B * h0; LS = MU + B * z;  // wide-layer path only
+    DF = LS + B * z;
     DF = (T *)(((uintptr_t)DF + 15) & ~(uintptr_t)15);
   }
 };
 
 // encoder tail + reparametrisation + decoder head, RB samples per workgroup.
 // H1 holds Y W1 on entry (no bias) and relu(Y W1 + b1) on exit.
-template <typename T>
+template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, const T *params,
                                                                const T *eps, T *H1, T *H2, T *SD,
                                                                T *Z, T *D1, T *D2, T *loss,
-                                                               T loss_const, int stage) {
+                                                               T loss_const) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *bufA = reinterpret_cast<T *>(smem_raw);  // [RB][max dim]
   const int mx = max(d.h0, max(d.h1, d.z));
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
   const int h0 = d.h0, h1 = d.h1, z = d.z;
-  if (stage) stage_mid<T>(P, params, bufC + RB * mx, d.n, h0, h1, z, tid);
+  stage_mid<T>(P, params, bufC + RB * mx, d.n, h0, h1, z, tid);
 
   // H1 = relu(A1 + b1)
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     bufA[idx] = v;
   }
   __syncthreads();
-  dense_fwd<T>(bufA, h0, P.W2, P.b2, h1, bufB, tid);  // A2
+  dense_fwd<T, RB>(bufA, h0, P.W2, P.b2, h1, bufB, tid);  // A2
   __syncthreads();
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
     const int r = idx / h1;
@@ -376,8 +392,8 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     if (r < rows) H2[(s0 + r) * h1 + idx % h1] = v;
   }
   __syncthreads();
-  dense_fwd<T>(bufB, h1, P.Wmu, P.bmu, z, bufA, tid);  // mu
-  dense_fwd<T>(bufB, h1, P.Wsd, P.bsd, z, bufC, tid);  // log sd
+  dense_fwd<T, RB>(bufB, h1, P.Wmu, P.bmu, z, bufA, tid);  // mu
+  dense_fwd<T, RB>(bufB, h1, P.Wsd, P.bsd, z, bufC, tid);  // log sd
   __syncthreads();
   T lsum = T(0);
   for (int idx = tid; idx < RB * z; idx += NTHREADS) {
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     bufB[idx] = zz;  // reuse bufB as Z (h1 >= ... not assumed: RB*z <= RB*mx)
   }
   __syncthreads();
-  dense_fwd<T>(bufB, z, P.V1, P.c1, h1, bufA, tid);  // G1
+  dense_fwd<T, RB>(bufB, z, P.V1, P.c1, h1, bufA, tid);  // G1
   __syncthreads();
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
     const int r = idx / h1;
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     if (r < rows) D1[(s0 + r) * h1 + idx % h1] = v;
   }
   __syncthreads();
-  dense_fwd<T>(bufA, h1, P.V2, P.c2, h0, bufC, tid);  // G2
+  dense_fwd<T, RB>(bufA, h1, P.V2, P.c2, h0, bufC, tid);  // G2
   __syncthreads();
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
     const int r = idx / h0;
@@ -422,13 +438,13 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
 }
 
 // the same chain backwards.  dD2 holds DF V3^T on entry; dA1 (gradient at Y W1 + b1) on exit.
-template <typename T>
+template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, const T *params,
                                                                T *grads, const T *eps,
                                                                const T *H1, const T *H2,
                                                                const T *SD, const T *Z,
                                                                const T *D1, const T *D2,
-                                                               const T *dD2, T *dA1, int stage) {
+                                                               const T *dD2, T *dA1) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int mx = max(d.h0, max(d.h1, d.z));
   T *act = reinterpret_cast<T *>(smem_raw);  // activations of the layer input
@@ -441,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
   const int h0 = d.h0, h1 = d.h1, z = d.z;
-  if (stage) stage_mid<T>(P, params, gC + RB * mx, d.n, h0, h1, z, tid);
+  stage_mid<T>(P, params, gC + RB * mx, d.n, h0, h1, z, tid);
   auto ld = [&](const T *src, int64_t r, int w, int j) { return r < rows ? src[(s0 + r) * w + j] : T(0); };
 
   // dG2 = dD2 * (D2 > 0);  act = D1
@@ -451,16 +467,16 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   }
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) act[idx] = ld(D1, idx / h1, h1, idx % h1);
   __syncthreads();
-  dense_bwd_w<T>(act, h1, gA, h0, (T *)G.V2, (T *)G.c2, rows, tid);
-  dense_bwd_in<T>(gA, h0, P.V2, h1, gB, tid);  // dD1
+  dense_bwd_w<T, RB>(act, h1, gA, h0, (T *)G.V2, (T *)G.c2, rows, tid);
+  dense_bwd_in<T, RB>(gA, h0, P.V2, h1, gB, tid);  // dD1
   __syncthreads();
   // dG1 = dD1 * (D1 > 0);  act = Z
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) gB[idx] = (act[idx] > T(0)) ? gB[idx] : T(0);
   __syncthreads();
   for (int idx = tid; idx < RB * z; idx += NTHREADS) act[idx] = ld(Z, idx / z, z, idx % z);
   __syncthreads();
-  dense_bwd_w<T>(act, z, gB, h1, (T *)G.V1, (T *)G.c1, rows, tid);
-  dense_bwd_in<T>(gB, h1, P.V1, z, gA, tid);  // dZ (decoder part)
+  dense_bwd_w<T, RB>(act, z, gB, h1, (T *)G.V1, (T *)G.c1, rows, tid);
+  dense_bwd_in<T, RB>(gB, h1, P.V1, z, gA, tid);  // dZ (decoder part)
   __syncthreads();
   // dmu = dZ + z ; dls = dZ * eps * sd - 1   -> gA = dmu, gC = dls ;  act = H2
   for (int idx = tid; idx < RB * z; idx += NTHREADS) {
@@ -472,19 +488,19 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   __syncthreads();
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) act[idx] = ld(H2, idx / h1, h1, idx % h1);
   __syncthreads();
-  dense_bwd_w<T>(act, h1, gA, z, (T *)G.Wmu, (T *)G.bmu, rows, tid);
-  dense_bwd_w<T>(act, h1, gC, z, (T *)G.Wsd, (T *)G.bsd, rows, tid);
-  dense_bwd_in<T>(gA, z, P.Wmu, h1, gB, tid);
+  dense_bwd_w<T, RB>(act, h1, gA, z, (T *)G.Wmu, (T *)G.bmu, rows, tid);
+  dense_bwd_w<T, RB>(act, h1, gC, z, (T *)G.Wsd, (T *)G.bsd, rows, tid);
+  dense_bwd_in<T, RB>(gA, z, P.Wmu, h1, gB, tid);
   __syncthreads();
-  dense_bwd_in<T>(gC, z, P.Wsd, h1, gB, tid, true);  // dH2
+  dense_bwd_in<T, RB>(gC, z, P.Wsd, h1, gB, tid, true);  // dH2
   __syncthreads();
   // dA2 = dH2 * (H2 > 0);  act = H1
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) gB[idx] = (act[idx] > T(0)) ? gB[idx] : T(0);
   __syncthreads();
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) act[idx] = ld(H1, idx / h0, h0, idx % h0);
   __syncthreads();
-  dense_bwd_w<T>(act, h0, gB, h1, (T *)G.W2, (T *)G.b2, rows, tid);
-  dense_bwd_in<T>(gB, h1, P.W2, h0, gA, tid);  // dH1
+  dense_bwd_w<T, RB>(act, h0, gB, h1, (T *)G.W2, (T *)G.b2, rows, tid);
+  dense_bwd_in<T, RB>(gB, h1, P.W2, h0, gA, tid);  // dH1
   __syncthreads();
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
     const int r = idx / h0, j = idx % h0;
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
 }
 
 // decoder head only (chains): Z -> D1 -> D2 (a11 forward), and its reverse (a11 VJP)
-template <typename T>
+template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, const T *dec_params,
                                                                const T *Zin, T *D1, T *D2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, con
   for (int idx = tid; idx < RB * z; idx += NTHREADS)
     bufA[idx] = (idx / z < rows) ? Zin[(s0 + idx / z) * z + idx % z] : T(0);
   __syncthreads();
-  dense_fwd<T>(bufA, z, V1, c1, h1, bufB, tid);
+  dense_fwd<T, RB>(bufA, z, V1, c1, h1, bufB, tid);
   __syncthreads();
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
     const T v = bufB[idx] > T(0) ? bufB[idx] : T(0);
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, con
     if (idx / h1 < rows) D1[(s0 + idx / h1) * h1 + idx % h1] = v;
   }
   __syncthreads();
-  dense_fwd<T>(bufB, h1, V2, c2, h0, bufA, tid);
+  dense_fwd<T, RB>(bufB, h1, V2, c2, h0, bufA, tid);
   __syncthreads();
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
     const T v = bufA[idx] > T(0) ? bufA[idx] : T(0);
@@ -524,7 +540,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, con
   }
 }
 
-template <typename T>
+template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void dec_mid_bwd_kernel(VaeDims<T> d, const T *dec_params,
                                                                const T *D1, const T *D2,
                                                                const T *dD2, T *dZ) {
@@ -542,17 +558,74 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_bwd_kernel(VaeDims<T> d, con
     gA[idx] = (r < rows && D2[(s0 + r) * h0 + j] > T(0)) ? dD2[(s0 + r) * h0 + j] : T(0);
   }
   __syncthreads();
-  dense_bwd_in<T>(gA, h0, V2, h1, gB, tid);
+  dense_bwd_in<T, RB>(gA, h0, V2, h1, gB, tid);
   __syncthreads();
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) {
     const int r = idx / h1, j = idx % h1;
     gB[idx] = (r < rows && D1[(s0 + r) * h1 + j] > T(0)) ? gB[idx] : T(0);
   }
   __syncthreads();
-  dense_bwd_in<T>(gB, h1, V1, z, gA, tid);
+  dense_bwd_in<T, RB>(gB, h1, V1, z, gA, tid);
   __syncthreads();
   for (int idx = tid; idx < RB * z; idx += NTHREADS)
     if (idx / z < rows) dZ[(s0 + idx / z) * z + idx % z] = gA[idx];
+}
+
+// ---- wide hidden layers: the same chain as MFMA tile products + elementwise kernels ------------------
+// Used when the mid-layer weights do not fit in LDS beside the activation buffers (e.g. the scaled
+// 512-256-64 MLP of SURVEY.md §8d): per-sample dense layers on the vector ALU then cost more than
+// the n-sized products around them.
+template <typename T>
+__global__ void bias_relu_kernel(int64_t count, int w, T *H, const T *__restrict__ bias) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const T v = H[i] + bias[i % w];
+    H[i] = v > T(0) ? v : T(0);
+  }
+}
+template <typename T>
+__global__ void relu_mask_kernel(int64_t count, T *G, const T *__restrict__ act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    G[i] = act[i] > T(0) ? G[i] : T(0);
+}
+// z = mu + exp(ls) eps (vae.py:83,135) and the latent terms of the loss; MU, LS are B x z
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void reparam_kernel(int64_t count, const T *__restrict__ MU,
+                                                           const T *__restrict__ LS,
+                                                           const T *__restrict__ eps, T *SD, T *Z,
+                                                           T *loss, T loss_const) {
+  __shared__ T red[4];
+  T lsum = T(0);
+  for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * NTHREADS) {
+    const T e = eps[i], ls = LS[i];
+    const T sd = dexp<T>(ls);
+    const T zz = MU[i] + sd * e;
+    SD[i] = sd;
+    Z[i] = zz;
+    lsum += T(0.5) * zz * zz - T(0.5) * e * e - ls;
+  }
+  lsum = wave_sum<T>(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + (blockIdx.x == 0 ? loss_const : T(0)));
+}
+// on entry MU holds dZ (decoder part); on exit MU = dmu = dZ + z, LS = dls = dmu eps sd - 1
+template <typename T>
+__global__ void latent_grad_kernel(int64_t count, T *MU, T *LS, const T *__restrict__ eps,
+                                   const T *__restrict__ SD, const T *__restrict__ Z) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const T dmu = MU[i] + Z[i];
+    MU[i] = dmu;
+    LS[i] = dmu * eps[i] * SD[i] - T(1);
+  }
+}
+static inline unsigned ew_blocks(int64_t count) {
+  const int64_t b = cdiv(count, (int64_t)NTHREADS * 4);
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 // ---- Adam (jax.experimental.optimizers.adam, as numpyro.optim.Adam wraps it) ------------------------
@@ -573,14 +646,69 @@ __global__ void adam_kernel(int64_t count, T *p, const T *g, T *m, T *v, T lr, T
 }
 
 // split K so that a launch has about 512 workgroups (2 per CU): measured best at the C3 shape —
-// more, shorter slices pay more prologue and atomics than they gain in memory parallelism
+// more, shorter slices pay more prologue and atomics than they gain in memory parallelism.  With more
+// than 512 tiles' worth of work per slice the count is rounded to fill whole rounds of 512: 320 tiles
+// (the scaled MLP's dV3) would otherwise leave a quarter of the CUs with twice the work of the rest.
 static inline int pick_splitk(int64_t tiles, int64_t K) {
-  int s = (int)(512 / (tiles > 0 ? tiles : 1));
-  if (s < 1) s = 1;
-  const int64_t maxs = cdiv(K, 4 * 32);  // at least 4 (f32) k-tiles per slice
-  if (s > maxs) s = (int)(maxs > 0 ? maxs : 1);
-  return s;
+  if (tiles < 1) tiles = 1;
+  int64_t maxs = cdiv(K, 4 * 32);  // at least 4 (f32) k-tiles per slice
+  if (maxs < 1) maxs = 1;
+  if (maxs > 32) maxs = 32;
+  int best = 1;
+  double best_eff = 0;
+  for (int s = 1; s <= maxs; ++s) {
+    const int64_t wgs = tiles * s;
+    const double eff = (double)wgs / (double)(cdiv(wgs, 512) * 512);
+    if (eff > best_eff + 0.05) { best_eff = eff; best = s; }  // the smallest s within 5 % of the best
+    if (wgs >= 4 * 512) break;
+  }
+  return best;
 }
+
+// C (M x N) = mask(relu([C +] A (M x K) W (K x N) [+ bias]))       (a dense layer forwards)
+template <typename T>
+static void dense_gemm(hipStream_t st, const T *A, int64_t M, int K, const T *W, int N, const T *bias,
+                       int relu, T *C) {
+  GemmArgs<T> g{};
+  g.A = A; g.lda = K; g.B = W; g.ldb = N; g.C = C; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
+  g.vec_a = kc_vec_ok<T>(A, K); g.vec_b = mc_vec_ok<T>(W, N);
+  launch_gemm<T, true, false, EPI_FUSED>(st, g, 1);
+}
+// C (M x K) = mask([C +] G (M x N) W^T)        (input gradient of a dense layer; W is K x N)
+template <typename T>
+static void dense_gemm_t(hipStream_t st, const T *G, int64_t M, int N, const T *W, int K, T *C,
+                         int addc, const T *mask) {
+  GemmArgs<T> g{};
+  g.A = G; g.lda = N; g.B = W; g.ldb = N; g.C = C; g.ldc = K;
+  g.M = M; g.N = K; g.K = N; g.addc = addc; g.mask = mask; g.ldm = K;
+  g.vec_a = kc_vec_ok<T>(G, N); g.vec_b = kc_vec_ok<T>(W, N);
+  launch_gemm<T, true, true, EPI_FUSED>(st, g, 1);
+}
+// [dW; db] += [A | 1]^T G      ((K+1) x N, summed over the M samples; W and b adjacent in the layout)
+template <typename T>
+static void dense_gemm_w(hipStream_t st, const T *A, int64_t M, int K, const T *G, int N, T *dW) {
+  GemmArgs<T> g{};
+  g.A = A; g.lda = K; g.B = G; g.ldb = N; g.C = dW; g.ldc = N;
+  g.M = K + 1; g.N = N; g.K = M; g.a_ones_row = K;
+  g.vec_a = mc_vec_ok<T>(A, K); g.vec_b = mc_vec_ok<T>(G, N);
+  launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(K + 1, GBM) * cdiv(N, GBN), M));
+}
+
+// samples per workgroup of the mid kernels: the backward kernel keeps four [RB][mx] buffers in LDS and a
+// launch may ask for 64 KB of it; h0, h1, z <= 1024 (check_dims) always leaves RB >= 2
+template <typename T> static inline int pick_rb(int mx, int nbuf) {
+  for (int rb : {16, 8, 4, 2})
+    if ((size_t)nbuf * rb * mx * sizeof(T) <= 64 * 1024) return rb;
+  return 0;
+}
+#define GPVAE_RB_SWITCH(rb, ...)                                   \
+  switch (rb) {                                                    \
+    case 16: { constexpr int RB = 16; __VA_ARGS__; } break;        \
+    case 8:  { constexpr int RB = 8;  __VA_ARGS__; } break;        \
+    case 4:  { constexpr int RB = 4;  __VA_ARGS__; } break;        \
+    default: { constexpr int RB = 2;  __VA_ARGS__; } break;        \
+  }
 
 template <typename T>
 static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, int z,
@@ -592,12 +720,16 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   VaeParams<T> P(params, n, h0, h1, z);
   VaeDims<T> dims{B, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
-  // the mid-layer weights are staged in LDS when they fit beside the activation buffers
+  // Small hidden layers (the reference's 35-30-10 / 50-30-15): the whole chain between the two n-sized
+  // layers runs per block of samples with its weights staged in LDS.  When weights + activation
+  // buffers do not fit the 64 KB a launch may ask for, every layer is a tile product instead.
   const size_t mid_bytes = (size_t)VaeParams<T>::mid_count(h0, h1, z) * sizeof(T);
-  const int stage = mid_bytes + 4 * (size_t)RB * mx * sizeof(T) <= 60 * 1024;  // default dynamic-LDS limit
-  const size_t shm_f = 3 * (size_t)RB * mx * sizeof(T) + (stage ? mid_bytes : 0);
-  const size_t shm_b = 4 * (size_t)RB * mx * sizeof(T) + (stage ? mid_bytes : 0);
-  const unsigned nblk = (unsigned)cdiv(B, RB);
+  const int rb = pick_rb<T>(mx, 4);
+  const bool wide = rb == 0 || mid_bytes + 4 * (size_t)rb * mx * sizeof(T) > 60 * 1024;
+  const size_t shm_f = 3 * (size_t)rb * mx * sizeof(T) + mid_bytes;
+  const size_t shm_b = 4 * (size_t)rb * mx * sizeof(T) + mid_bytes;
+  const unsigned nblk = (unsigned)cdiv(B, rb > 0 ? rb : 1);
+  const int64_t Bz = B * z;
   const T inv_var = (T)(1.0 / (obs_sigma * obs_sigma));
   // constant of the data term: B*n*(log sigma + 0.5 log 2pi)
   const T loss_const = (T)((double)B * (double)n * (log(obs_sigma) + 0.9189385332046727));
@@ -611,8 +743,21 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
     g.vec_a = kc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(P.W1, h0);
     launch_gemm<T, true, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
   }
-  hipLaunchKernelGGL((vae_mid_fwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_f, st, dims, params,
-                     eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss, loss_const, stage);
+  if (!wide) {
+    GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_fwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm_f,
+                                           st, dims, params, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss,
+                                           loss_const));
+  } else {
+    hipLaunchKernelGGL((bias_relu_kernel<T>), dim3(ew_blocks(B * h0)), dim3(NTHREADS), 0, st, B * h0, h0,
+                       W.H1, P.b1);
+    dense_gemm<T>(st, W.H1, B, h0, P.W2, h1, P.b2, 1, W.H2);
+    dense_gemm<T>(st, W.H2, B, h1, P.Wmu, z, P.bmu, 0, W.MU);
+    dense_gemm<T>(st, W.H2, B, h1, P.Wsd, z, P.bsd, 0, W.LS);
+    hipLaunchKernelGGL((reparam_kernel<T>), dim3(ew_blocks(Bz)), dim3(NTHREADS), 0, st, Bz, W.MU, W.LS, eps,
+                       W.SD, W.Z, loss, loss_const);
+    dense_gemm<T>(st, W.Z, B, z, P.V1, h1, P.c1, 1, W.D1);
+    dense_gemm<T>(st, W.D1, B, h1, P.V2, h0, P.c2, 1, W.D2);
+  }
   {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
     GemmArgs<T> g{};
     g.A = W.D2; g.lda = h0; g.B = P.V3; g.ldb = n; g.C = W.DF; g.ldc = n;
@@ -639,8 +784,27 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
       g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
       launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
     }
-    hipLaunchKernelGGL((vae_mid_bwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm_b, st, dims,
-                       params, grads, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, W.dD2, W.dA1, stage);
+    if (!wide) {
+      GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_bwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS),
+                                             shm_b, st, dims, params, grads, eps, W.H1, W.H2, W.SD, W.Z,
+                                             W.D1, W.D2, W.dD2, W.dA1));
+    } else {
+      // gradient buffers reuse the activations they mask: dG2 in dD2, dG1 then dA2 in D1, dmu | dls in MU | LS
+      hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(B * h0)), dim3(NTHREADS), 0, st, B * h0,
+                         W.dD2, W.D2);                                      // dG2
+      dense_gemm_w<T>(st, W.D1, B, h1, W.dD2, h0, (T *)G.V2);              // dV2 | dc2
+      dense_gemm_t<T>(st, W.dD2, B, h0, P.V2, h1, W.D1, 0, W.D1);          // dG1 = (dG2 V2^T) (D1 > 0)
+      dense_gemm_w<T>(st, W.Z, B, z, W.D1, h1, (T *)G.V1);                 // dV1 | dc1
+      dense_gemm_t<T>(st, W.D1, B, h1, P.V1, z, W.MU, 0, (const T *)nullptr);  // dZ (decoder part)
+      hipLaunchKernelGGL((latent_grad_kernel<T>), dim3(ew_blocks(Bz)), dim3(NTHREADS), 0, st, Bz, W.MU, W.LS,
+                         eps, W.SD, W.Z);
+      dense_gemm_w<T>(st, W.H2, B, h1, W.MU, z, (T *)G.Wmu);               // dWmu | dbmu
+      dense_gemm_w<T>(st, W.H2, B, h1, W.LS, z, (T *)G.Wsd);               // dWsd | dbsd
+      dense_gemm_t<T>(st, W.MU, B, z, P.Wmu, h1, W.D1, 0, (const T *)nullptr);
+      dense_gemm_t<T>(st, W.LS, B, z, P.Wsd, h1, W.D1, 1, W.H2);           // dA2 = (dmu Wmu^T + dls Wsd^T) (H2 > 0)
+      dense_gemm_w<T>(st, W.H1, B, h0, W.D1, h1, (T *)G.W2);               // dW2 | db2
+      dense_gemm_t<T>(st, W.D1, B, h1, P.W2, h0, W.dA1, 0, W.H1);          // dA1 = (dA2 W2^T) (H1 > 0)
+    }
     {  // [dW1; db1] += [Y | 1]^T dA1        ((n+1) x h0; W1 and b1 are adjacent in the layout)
       GemmArgs<T> g{};
       g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = (T *)G.W1; g.ldc = h0;
@@ -662,10 +826,19 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
   T *D1 = (T *)work_v, *D2 = D1 + C * h1, *dD2 = D2 + C * h0;
   VaeDims<T> dims{C, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
-  const size_t shm = 2 * (size_t)RB * mx * sizeof(T);
-  const unsigned nblk = (unsigned)cdiv(C, RB);
-  hipLaunchKernelGGL((dec_mid_fwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm, st, dims, dec,
-                     (const T *)Z_v, D1, D2);
+  // as in run_vae_elbo: per-sample-block kernels for the reference's small heads, tile products when wide
+  const int rb = pick_rb<T>(mx, 2);
+  const bool wide = rb == 0 || (int64_t)z * h1 + (int64_t)h1 * h0 > 8192;
+  const size_t shm = 2 * (size_t)rb * mx * sizeof(T);
+  const unsigned nblk = (unsigned)cdiv(C, rb > 0 ? rb : 1);
+  const T *V1 = dec, *c1 = V1 + (int64_t)z * h1, *V2 = c1 + h1, *c2 = V2 + (int64_t)h1 * h0;
+  if (!wide) {
+    GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((dec_mid_fwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm, st,
+                                           dims, dec, (const T *)Z_v, D1, D2));
+  } else {
+    dense_gemm<T>(st, (const T *)Z_v, C, z, V1, h1, c1, 1, D1);
+    dense_gemm<T>(st, D1, C, h1, V2, h0, c2, 1, D2);
+  }
   if (!vjp) {  // F = D2 V3 + c3
     GemmArgs<T> g{};
     g.A = D2; g.lda = h0; g.B = V3; g.ldb = n; g.C = (T *)out_v; g.ldc = n;
@@ -679,8 +852,14 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
     g.vec_a = kc_vec_ok<T>(dF_v, n); g.vec_b = kc_vec_ok<T>(V3, n);
     (void)hipMemsetAsync(dD2, 0, sizeof(T) * C * h0, st);
     launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(C, GBM) * cdiv(h0, GBN), n));
-    hipLaunchKernelGGL((dec_mid_bwd_kernel<T>), dim3(nblk), dim3(NTHREADS), shm, st, dims, dec, D1,
-                       D2, dD2, (T *)out_v);
+    if (!wide) {
+      GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((dec_mid_bwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm,
+                                             st, dims, dec, D1, D2, dD2, (T *)out_v));
+    } else {
+      hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(C * h0)), dim3(NTHREADS), 0, st, C * h0, dD2, D2);
+      dense_gemm_t<T>(st, dD2, C, h0, V2, h1, D1, 0, D1);  // (dG2 V2^T) (D1 > 0), over D1
+      dense_gemm_t<T>(st, D1, C, h1, V1, z, (T *)out_v, 0, (const T *)nullptr);
+    }
   }
   GPVAE_CHECK_LAUNCH(vjp ? "gpvae_decoder_vjp" : "gpvae_decoder_fwd");
   return 0;

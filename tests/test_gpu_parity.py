@@ -437,6 +437,32 @@ def test_vae_elbo_reference_dims(ops, ndt, tdt, tol, dims):
         assert rel(gd[k], go[k]) < t, k
 
 
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("dims", [(64, 256, 512, 256, 64), (300, 100, 1024, 700, 33), (9, 40, 8, 1024, 1024), (13, 50, 600, 2, 2)])
+def test_vae_wide_hidden_layers(ops, ndt, tdt, tol, dims):
+    """SURVEY §8d's scaled MLP (512, 256, 64) and the API's widest layers (1024): every layer runs as a
+    tile product (EPI_FUSED) when the mid weights do not fit LDS; (600, 2, 2) keeps the per-sample-block
+    kernels but with a smaller block (16 -> 8/4/2 samples) so the activation buffers stay inside 64 KB.
+    ELBO + gradients, decoder forward and its VJP against the oracle."""
+    B, n, h0, h1, z = dims
+    rng = np.random.default_rng(15)
+    p = {k: (3 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+    lo, go = orc.elbo_loss_and_grads(p, Y, ez, 0.1)
+    flat = dev(orc.flatten(p), tdt)
+    grads = torch.empty_like(flat)
+    loss = ops.vae_elbo(flat, dev(Y, tdt), dev(ez, tdt), (h0, h1, z), 0.1, grads=grads)
+    t = 1e-10 if ndt == np.float64 else 1e-4
+    assert abs(loss.item() - lo) < t * abs(lo)
+    gd = orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+    for k in orc.PARAM_NAMES:
+        assert rel(gd[k], go[k]) < t, k
+    decp = dev(np.concatenate([p[k].reshape(-1) for k in ("V1", "c1", "V2", "c2", "V3", "c3")]), tdt)
+    dF = rng.standard_normal((B, n))
+    assert rel(ops.decoder_fwd(decp, dev(ez, tdt), n, h0, h1), orc.decoder(p, ez)) < t
+    assert rel(ops.decoder_vjp(decp, dev(ez, tdt), dev(dF, tdt), h0, h1), orc.decoder_vjp(p, ez, dF)) < t
+
+
 def test_vae_elbo_full_size_c3(ops):
     """The bench shape (B = n = 4096, 50-30-15, fp32) against the oracle: every fast path of the tile
     products (VALU-free k loops, ragged-K through the buffer range check, TileIO epilogues, split-K

@@ -22,18 +22,38 @@ def timed(f, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-if "c2" in which:  # 1D grid n=1024, B=4096, reference MLP (35,30,10), fp32, jitter 1e-4
-    n, B, dims = 1024, 4096, (35, 30, 10)
-    x = torch.arange(n, dtype=torch.float32, device=dev) / n
-    eng = StepEngine(x, 1e-4, dims, B, 1e-3, dtype=torch.float32, seed=1, group=16)  # priors of vae.py:157-159
+def train_rate(tag, x, jitter, dims, B, steps, hyper_sampler=None, group=16):
+    """draws/s of the whole training step (hyper draw -> Gram -> potrf -> draw -> ELBO -> Adam)."""
+    n = x.shape[0]
+    kw = {} if hyper_sampler is None else {"hyper_sampler": hyper_sampler}
+    eng = StepEngine(x, jitter, dims, B, 1e-3, dtype=torch.float32, seed=1, group=group, **kw)  # priors of vae.py:157-159
     st = SVIState(init_params(n, *dims, 1, torch.float32, dev))
     eng.run([(0, i) for i in range(16)], st, train=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    steps = 128
     eng.run([(1, i) for i in range(steps)], st, train=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"config": "C2: 1D n=1024, B=4096, VAE 1024-35-30-10, f32", "draws_per_s": B * steps / dt,
-                      "ms_per_step": dt / steps * 1e3, "final_loss": float(eng.loss.item())}), flush=True)
+    print(json.dumps({"config": tag, "draws_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3,
+                      "final_loss": float(eng.loss.item())}), flush=True)
+
+
+def beta_hyper(rng, size=None):
+    """the README's lengthscale prior Beta(0.1, 2.0) (README.md:17) in place of InverseGamma(1, 0.1);
+    floored at 1e-3: Beta(0.1, 2) puts mass at ls -> 0, where the Gram matrix is the identity."""
+    ls = np.maximum(rng.beta(0.1, 2.0, size=size), 1e-3)
+    return ls, np.exp(0.1 * rng.standard_normal(size=size)), np.abs(0.1 * rng.standard_normal(size=size))
+
+
+if "c2" in which:  # 1D grid n=1024, B=4096, fp32, jitter 1e-4: reference MLP (35,30,10), scaled MLP, README prior
+    x1 = torch.arange(1024, dtype=torch.float32, device=dev) / 1024
+    train_rate("C2: 1D n=1024, B=4096, VAE 1024-35-30-10, f32", x1, 1e-4, (35, 30, 10), 4096, 128)
+    train_rate("C2 scaled: 1D n=1024, B=4096, VAE 1024-512-256-64, f32", x1, 1e-4, (512, 256, 64), 4096, 64)
+    train_rate("C2 README prior: ls ~ Beta(0.1, 2.0), VAE 1024-35-30-10, f32", x1, 1e-4, (35, 30, 10), 4096, 128, beta_hyper)
+
+if "c3s" in which:  # the bench grid with the scaled MLP
+    g = torch.arange(64, dtype=torch.float32, device=dev) / 64
+    u, v = torch.meshgrid(g, g, indexing="xy")
+    x2 = torch.stack([u.reshape(-1), v.reshape(-1)], 1).contiguous()
+    train_rate("C3 scaled: 64x64 grid, B=4096, VAE 4096-512-256-64, f32", x2, 1e-3, (512, 256, 64), 4096, 32)
 
 if "c4" in which:  # kriging, 192x192 grid, 32768 observations, fp64
     g = np.arange(192) / 192.0
