@@ -460,30 +460,75 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
 }
 
 // ---- outer trailing update: C[r][c] -= sum_{k in [cJ, cJ+kb)} P[r][k] P[c][k] ----------------------
-// 128x128 tiles, 4 waves as 2x2, each 64x64.  Grid (row tiles, col tiles, batch); tiles strictly
-// above the diagonal exit at once.
+// 128x128 tiles, 4 waves as 2x2, each 64x64.  One workgroup per tile on or below the diagonal
+// (ct (ct+1)/2 of them) plus the (rt - ct) x ct rectangle of the extra rows, in a 1-D grid.
+// The hardware deals consecutive workgroup ids to the 8 XCDs in turn.  A (row tiles, col tiles) grid
+// whose row-tile count is a multiple of 8 therefore gives XCD x the tile rows = x (mod 8), and row
+// r holds r + 1 tiles: at 16 tile rows XCD 7 had 2.4x the work of XCD 0 (62 instead of ~95 TFLOP/s
+// for that launch).  Here id -> (xcd = id % 8, k = id / 8); XCD x owns the matrices b = x (mod 8) and
+// walks their tiles in row-major order, so its L2 holds the panels of one matrix at a time and every
+// XCD has the same number of tiles.  With fewer than 8 matrices the tiles are dealt round-robin.
 constexpr int SBM = 128;
+
+struct SyrkMap {
+  int rt, ct, batch;
+  int64_t per;  // tiles per matrix
+  __host__ __device__ static int64_t tiles(int rt, int ct) {
+    return (int64_t)ct * (ct + 1) / 2 + (int64_t)(rt - ct) * ct;
+  }
+  __host__ int64_t grid() const {
+    return batch >= 8 ? 8 * (int64_t)((batch + 7) / 8) * per : (int64_t)batch * per;
+  }
+  // false: this workgroup has nothing to do
+  __device__ __forceinline__ bool decode(int64_t id, int &b, int &tr, int &tc) const {
+    int64_t p;
+    if (batch >= 8) {
+      const int xcd = (int)(id & 7);
+      const int64_t k = id >> 3;
+      const int64_t mb = k / per;
+      b = xcd + 8 * (int)mb;
+      if (b >= batch) return false;
+      p = k - mb * per;
+    } else {
+      b = (int)(id / per);
+      p = id - (int64_t)b * per;
+    }
+    const int64_t ntri = (int64_t)ct * (ct + 1) / 2;
+    if (p < ntri) {
+      int r = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+      while ((int64_t)r * (r + 1) / 2 > p) --r;
+      while ((int64_t)(r + 1) * (r + 2) / 2 <= p) ++r;
+      tr = r;
+      tc = (int)(p - (int64_t)r * (r + 1) / 2);
+    } else {
+      const int64_t q = p - ntri;
+      tr = ct + (int)(q / ct);
+      tc = (int)(q % ct);
+    }
+    return true;
+  }
+};
 
 template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
-    VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cJ, int64_t kend) {
+    VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cJ, int64_t kend, SyrkMap map) {
   using M = Mfma<T>;
   constexpr int SBK = TileK<T>::BK;
   constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
   constexpr int LD = SBK + RmPad<T>::V;  // row-major images [128][LD]
-  if (blockIdx.x < blockIdx.y) return;
+  int b, tr, tc;
+  if (!map.decode(blockIdx.x, b, tr, tc)) return;
   using LA = LoaderKC<T, SBM, SBK, VECM>;
   using Pipe = PipeKC<T, F, F, SBK, SBM, SBM, LA, LA>;
   static_assert(Pipe::LD == LD, "image stride");
   __shared__ __align__(16) T lds[Pipe::LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z;
   vr.A += (int64_t)b * strideA;
   if (vr.X) vr.X += (int64_t)b * strideX;
   const int64_t n = vr.n;
-  const int64_t r0 = kend + (int64_t)blockIdx.x * SBM;  // first virtual row of the tile
-  const int64_t q0 = kend + (int64_t)blockIdx.y * SBM;  // first column of the tile (< n)
-  const bool diag_tile = blockIdx.x == blockIdx.y;
+  const int64_t r0 = kend + (int64_t)tr * SBM;  // first virtual row of the tile
+  const int64_t q0 = kend + (int64_t)tc * SBM;  // first column of the tile (< n)
+  const bool diag_tile = tr == tc;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   LA la, lb;
@@ -558,9 +603,10 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
   T *Ab = A + (int64_t)b * strideA;
   const bool failed = (flags & GPVAE_POTRF_NAN_ON_FAIL) && info[b] != 0;
   const bool zero_up = flags & GPVAE_POTRF_ZERO_UPPER;
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
   const int64_t i0 = (int64_t)blockIdx.y * NB;
+  // without flags only the diagonal blocks are touched: one 64-thread block per diagonal block
+  const int64_t j = flags ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : i0 + threadIdx.x;
+  if (j >= n) return;
   const int64_t i1 = (i0 + NB < n) ? i0 + NB : n;
   const bool in_diag = j >= i0 && j < i0 + NB;  // this column crosses the strip's diagonal block
   if (!failed && !in_diag && (!zero_up || j < i0)) return;  // nothing to do for this column strip
@@ -593,15 +639,16 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
                          g_stamps);
     }
     if (kend < n) {
-      const int64_t rt = cdiv(Mv - kend, SBM), ct = cdiv(n - kend, SBM);
-      hipLaunchKernelGGL((potrf_syrk_kernel<T, VECM>),
-                         dim3((unsigned)rt, (unsigned)ct, (unsigned)batch), dim3(NTHREADS), 0, st, vr,
-                         strideA, strideX, cJ, kend);
+      const int rt = (int)cdiv(Mv - kend, SBM), ct = (int)cdiv(n - kend, SBM);
+      const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+      hipLaunchKernelGGL((potrf_syrk_kernel<T, VECM>), dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st,
+                         vr, strideA, strideX, cJ, kend, map);
     }
   }
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
-                     dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(n, NB), (unsigned)batch), dim3(256),
-                     0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info, flags);
+                     dim3(flags ? (unsigned)cdiv(n, 256) : 1u, (unsigned)cdiv(n, NB), (unsigned)batch),
+                     dim3(flags ? 256 : NB), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
+                     flags);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
 }
@@ -653,7 +700,11 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
   GPVAE_REQUIRE(info, 12, "gpvae_potrf: info is NULL");
   GPVAE_REQUIRE(work && aligned16(work), 14,
                 "gpvae_potrf: work is NULL or not 16-byte aligned (gpvae_potrf_workspace_bytes)");
-  GPVAE_REQUIRE(cdiv(round_up(n, NB) + m_extra, SBM) <= 65535, 3, "gpvae_potrf: too many rows");
+  {  // the trailing update is one 1-D launch over all tiles of all matrices
+    const int rt = (int)cdiv(round_up(n, NB) + m_extra, SBM), ct = (int)cdiv(n, SBM);
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 4, "gpvae_potrf: batch x tiles exceeds one launch; split the batch");
+  }
   hipStream_t st = (hipStream_t)stream;
   if (m_extra == 0) X = nullptr;
   return dtype == GPVAE_F32
