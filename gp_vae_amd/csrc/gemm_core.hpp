@@ -564,15 +564,17 @@ struct PipeKC {
             acc[fm][fn] = M::mma(ha[HALF][c][fm][j], hb[HALF][c][fn][j], acc[fm][fn]);
   }
 
-  // one k-tile; CUR compile-time so every LDS offset is an immediate
+  // one k-tile; CUR compile-time so every LDS offset is an immediate.  FAST: tiles t+1 and t+2
+  // exist and are plain (no masking).  Otherwise they may not exist; `plain` (uniform) says that
+  // what exists needs no masking and keeps the tile free of vector-ALU work all the same.
   template <int CUR, bool FAST>
   __device__ __forceinline__ void tile(LA &la, LB &lb, T *lds, int aoff, int boff, int64_t k,
                                        int64_t kend, int tid, bool compute,
-                                       typename M::acc_t (&acc)[FM][FN]) {
+                                       typename M::acc_t (&acc)[FM][FN], bool plain = false) {
     constexpr int NXT = CUR ^ 1;
     const bool has1 = FAST || k + BK < kend, has2 = FAST || k + 2 * BK < kend;
     if (has1) {
-      if constexpr (FAST) {
+      if (FAST || plain) {
         la.template store_fast<LD>(lds + NXT * SZ, tid);
         lb.template store_fast<LD>(lds + NXT * SZ + RA * LD, tid);
       } else {
@@ -581,7 +583,7 @@ struct PipeKC {
       }
     }
     if (has2) {
-      if constexpr (FAST) {
+      if (FAST || plain) {
         la.load_fast(k + 2 * BK, kend);
         lb.load_fast(k + 2 * BK, kend);
       } else {
@@ -651,9 +653,11 @@ struct PipeKC {
       tile<1, true>(la, lb, lds, aoff, boff, k + BK, kend, tid, compute, acc);
     }
     const int nrest = (int)((kend - k + BK - 1) / BK);
+    // the whole k range plain: the last tiles keep off the masked (vector-ALU) store path too
+    const bool plain = nplain >= 2 && kbeg + (int64_t)nplain * BK >= kend;
     for (int i = 0; i < nrest; i += 2, k += 2 * BK) {
-      tile<0, false>(la, lb, lds, aoff, boff, k, kend, tid, compute, acc);
-      if (i + 1 < nrest) tile<1, false>(la, lb, lds, aoff, boff, k + BK, kend, tid, compute, acc);
+      tile<0, false>(la, lb, lds, aoff, boff, k, kend, tid, compute, acc, plain);
+      if (i + 1 < nrest) tile<1, false>(la, lb, lds, aoff, boff, k + BK, kend, tid, compute, acc, plain);
     }
   }
 };
