@@ -338,13 +338,25 @@ static inline int64_t vae_param_count(int64_t n, int h0, int h1, int z) {
 
 // workspace carve-up (elements of T)
 template <typename T> struct VaeWork {
-  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *MU, *LS, *DF;
-  static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
-    return B * (4 * (int64_t)h0 + 2 * (int64_t)h1 + 4 * (int64_t)z) + B * n + 64;
+  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *MU, *LS, *REP, *DF;
+  // REP: GREP copies of the mid-layer gradients (small-MLP path): workgroup i adds into copy
+  // i % GREP, so an address sees B/16/GREP atomics instead of B/16 (same-address float atomics
+  // serialise at the memory side: 256 deep they were two thirds of vae_mid_bwd_kernel's time)
+  static constexpr int GREP = 16;
+  static int64_t rep_elems(int h0, int h1, int z) {
+    const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);
+    return mc <= 15360 ? GREP * mc : 0;  // only dims whose mid weights can be staged in LDS (60 KB)
   }
+  static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
+    return B * (4 * (int64_t)h0 + 2 * (int64_t)h1 + 4 * (int64_t)z) + rep_elems(h0, h1, z) + B * n + 64;
+  }
+  // H1, dD2 and REP start from zero (split-K / replicated atomics): adjacent, one memset (zero_bytes)
+  int64_t zero_elems;
   __host__ VaeWork(T *w, int64_t B, int64_t n, int h0, int h1, int z) {
-    H1 = w;            H2 = H1 + B * h0;   SD = H2 + B * h1;   Z = SD + B * z;
-    D1 = Z + B * z;    D2 = D1 + B * h1;   dD2 = D2 + B * h0;  dA1 = dD2 + B * h0;
+    H1 = w;            dD2 = H1 + B * h0;  REP = dD2 + B * h0;
+    zero_elems = 2 * B * h0 + rep_elems(h0, h1, z);
+    H2 = H1 + zero_elems;  SD = H2 + B * h1;   Z = SD + B * z;
+    D1 = Z + B * z;    D2 = D1 + B * h1;   dA1 = D2 + B * h0;
     MU = dA1 + B * h0; LS = MU + B * z;  // wide-layer path only
     DF = LS + B * z;
     DF = (T *)(((uintptr_t)DF + 15) & ~(uintptr_t)15);
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
                                                                const T *H1, const T *H2,
                                                                const T *SD, const T *Z,
                                                                const T *D1, const T *D2,
-                                                               const T *dD2, T *dA1) {
+                                                               const T *dD2, T *dA1, T *rep) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int mx = max(d.h0, max(d.h1, d.z));
   T *act = reinterpret_cast<T *>(smem_raw);  // activations of the layer input
@@ -452,7 +464,10 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   T *gB = gA + RB * mx;
   T *gC = gB + RB * mx;
   VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
-  const VaeParams<T> G(grads, d.n, d.h0, d.h1, d.z);  // same layout; const-cast below
+  // the mid-layer gradients go to copy blockIdx.x % GREP of `rep` (vae_mid_reduce_kernel sums them)
+  VaeParams<T> G(grads, d.n, d.h0, d.h1, d.z);  // same layout; const-cast below
+  G.relocate_mid(rep + (int64_t)(blockIdx.x % VaeWork<T>::GREP) * VaeParams<T>::mid_count(d.h0, d.h1, d.z),
+                 d.h0, d.h1, d.z);
   const int tid = threadIdx.x;
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
@@ -506,6 +521,18 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
     const int r = idx / h0, j = idx % h0;
     if (r < rows) dA1[(s0 + r) * h0 + j] = (act[idx] > T(0)) ? gA[idx] : T(0);
   }
+}
+
+// grads[n*h0 + i] = sum over the GREP copies, i in [h0, mid_count): everything of the mid run but b1
+// (whose gradient is the ones row of the dW1 product)
+template <typename T>
+__global__ void vae_mid_reduce_kernel(int64_t mc, int h0, const T *__restrict__ rep, T *gmid) {
+  const int64_t i = h0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mc) return;
+  T a = T(0);
+#pragma unroll
+  for (int r = 0; r < VaeWork<T>::GREP; ++r) a += rep[r * mc + i];
+  gmid[i] = a;
 }
 
 // decoder head only (chains): Z -> D1 -> D2 (a11 forward), and its reverse (a11 VJP)
@@ -735,7 +762,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   const T loss_const = (T)((double)B * (double)n * (log(obs_sigma) + 0.9189385332046727));
 
   (void)hipMemsetAsync(loss, 0, sizeof(T), st);
-  (void)hipMemsetAsync(W.H1, 0, sizeof(T) * B * h0, st);
+  (void)hipMemsetAsync(W.H1, 0, sizeof(T) * (grads != nullptr ? W.zero_elems : B * h0), st);
   {  // A1 += Y W1
     GemmArgs<T> g{};
     g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.H1; g.ldc = h0;
@@ -769,7 +796,6 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   if (grads != nullptr) {
     VaeParams<T> G(grads, n, h0, h1, z);
     (void)hipMemsetAsync(grads, 0, sizeof(T) * vae_param_count(n, h0, h1, z), st);
-    (void)hipMemsetAsync(W.dD2, 0, sizeof(T) * B * h0, st);
     {  // [dV3; dc3] += [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
       GemmArgs<T> g{};
       g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
@@ -785,9 +811,12 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
       launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
     }
     if (!wide) {
+      const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);
       GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_bwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS),
                                              shm_b, st, dims, params, grads, eps, W.H1, W.H2, W.SD, W.Z,
-                                             W.D1, W.D2, W.dD2, W.dA1));
+                                             W.D1, W.D2, W.dD2, W.dA1, W.REP));
+      hipLaunchKernelGGL((vae_mid_reduce_kernel<T>), dim3((unsigned)cdiv(mc - h0, 256)), dim3(256), 0, st,
+                         mc, h0, W.REP, grads + n * h0);
     } else {
       // gradient buffers reuse the activations they mask: dG2 in dD2, dG1 then dA2 in D1, dmu | dls in MU | LS
       hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(B * h0)), dim3(NTHREADS), 0, st, B * h0,
