@@ -293,6 +293,29 @@ def test_kriging(ops, golden, ndt, tdt, tol):
         assert np.abs(vd.cpu().numpy() - vo).max() < 1e-8
 
 
+def test_kriging_mid_size_f64(ops):
+    """C4's arithmetic at a size the oracle's literal inverse-based form finishes in seconds
+    (48x48 grid, 2000 observations, f64): every blocked path of the factorisation with trailing rows
+    (outer blocks, panel chunks, extra-row tiles of the trailing update) against inference.py:442-460."""
+    g = np.arange(48) / 48.0
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1)
+    rng = np.random.default_rng(3)
+    obs = np.sort(rng.permutation(x.shape[0])[:2000])
+    y = np.full(x.shape[0], np.nan)
+    y[obs] = np.sin(5 * x[obs, 0]) * np.cos(3 * x[obs, 1]) + 0.05 * rng.standard_normal(2000)
+    mask = np.ones(x.shape[0], bool); mask[obs] = False
+    xi = rng.standard_normal(int(mask.sum()))
+    m_ref, s_ref, v_ref = orc.gp_prediction(x, y, obs, 1.3, 0.15, 0.05, xi)
+    xt = torch.tensor(x, dtype=torch.float64, device=DEV)
+    mean, samp, var_out, info = ops.krig_predict(xt[torch.tensor(obs, device=DEV)], xt[torch.tensor(np.nonzero(mask)[0], device=DEV)],
+                                                 torch.tensor(y[obs], dtype=torch.float64, device=DEV), 1.3, 0.15, 0.05, 1e-5,
+                                                 torch.tensor(xi, dtype=torch.float64, device=DEV))
+    assert int(info.item()) == 0
+    assert rel(mean, m_ref) < 1e-9 and rel(samp, s_ref) < 1e-9   # north_star: 1e-5 rel in fp64
+    assert np.abs(var_out.cpu().numpy() - np.maximum(v_ref, 0)).max() < 1e-9
+
+
 def test_gpinference_surface(ops, golden):
     from gp_vae_amd.gp import exp_kernel2
     from gp_vae_amd.inference import GPInference

@@ -22,12 +22,12 @@ def timed(f, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def train_rate(tag, x, jitter, dims, B, steps, hyper_sampler=None, group=16):
+def train_rate(tag, x, jitter, dims, B, steps, hyper_sampler=None, group=16, dtype=torch.float32):
     """draws/s of the whole training step (hyper draw -> Gram -> potrf -> draw -> ELBO -> Adam)."""
     n = x.shape[0]
     kw = {} if hyper_sampler is None else {"hyper_sampler": hyper_sampler}
-    eng = StepEngine(x, jitter, dims, B, 1e-3, dtype=torch.float32, seed=1, group=group, **kw)  # priors of vae.py:157-159
-    st = SVIState(init_params(n, *dims, 1, torch.float32, dev))
+    eng = StepEngine(x.to(dtype), jitter, dims, B, 1e-3, dtype=dtype, seed=1, group=group, **kw)  # priors of vae.py:157-159
+    st = SVIState(init_params(n, *dims, 1, dtype, dev))
     eng.run([(0, i) for i in range(16)], st, train=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     eng.run([(1, i) for i in range(steps)], st, train=True)
@@ -54,6 +54,20 @@ if "c3s" in which:  # the bench grid with the scaled MLP
     u, v = torch.meshgrid(g, g, indexing="xy")
     x2 = torch.stack([u.reshape(-1), v.reshape(-1)], 1).contiguous()
     train_rate("C3 scaled: 64x64 grid, B=4096, VAE 4096-512-256-64, f32", x2, 1e-3, (512, 256, 64), 4096, 32)
+    train_rate("C3 f64: 64x64 grid, B=4096, VAE 4096-50-30-15, f64", x2, 1e-3, (50, 30, 15), 4096, 64, dtype=torch.float64)
+
+if "c4cpu" in which:  # host LAPACK dpotrf at growing n, extrapolated ~ n^3 to the C4 size
+    import scipy.linalg
+    rng = np.random.default_rng(0)
+    out = {"config": "C4 CPU baseline: scipy.linalg.cholesky f64 (LAPACK dpotrf), host threads = %s" % os.environ.get("OMP_NUM_THREADS", "default")}
+    for nn in (4096, 8192):
+        g = rng.standard_normal((nn, 64))
+        a = g @ g.T + nn * np.eye(nn)
+        t0 = time.perf_counter(); scipy.linalg.cholesky(a, lower=True, overwrite_a=True, check_finite=False); t = time.perf_counter() - t0
+        out["potrf_s_n%d" % nn] = t
+        out["gflops_n%d" % nn] = nn ** 3 / 3 / t / 1e9
+    out["potrf_s_n32768_extrapolated"] = out["potrf_s_n8192"] * 64
+    print(json.dumps(out), flush=True)
 
 if "c4" in which:  # kriging, 192x192 grid, 32768 observations, fp64
     g = np.arange(192) / 192.0
