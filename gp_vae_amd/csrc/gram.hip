@@ -14,6 +14,29 @@ constexpr int GRAM_TX = 64;    // lanes along columns, 4 columns each => 256 col
 constexpr int GRAM_TY = 4;     // waves per block, one row each per iteration
 constexpr int GRAM_ROWS = 32;  // rows per block
 
+// exp(-0.5 (sqrt(s) / ls)^2), the reference's order of operations (norm, divide, square, exp).
+// f32: with libm's sqrtf / IEEE division / expf the kernel is bound by the vector ALU at 2.6 TB/s
+// of stores (about 45 instructions per entry), not by HBM.  Here: v_sqrt_f32 (1 ulp), a multiply
+// by 1/ls, and exp as v_exp_f32 of x log2(e) with the product's rounding error carried along
+// (2^(hi+lo) = 2^hi (1 + lo ln 2)): 3 ulp on the entry, about 14 instructions.
+template <typename T> struct GramMath {
+  __device__ static __forceinline__ T expq(T s, T inv_ls) {
+    const T q = dsqrt<T>(s) * inv_ls;
+    return dexp<T>(T(-0.5) * (q * q));
+  }
+};
+template <> struct GramMath<float> {
+  __device__ static __forceinline__ float expq(float s, float inv_ls) {
+    const float q = __builtin_amdgcn_sqrtf(s) * inv_ls;
+    const float x = -0.5f * (q * q);
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E, -hi) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e, lo * 0.693147182464599609375f, e);
+  }
+};
+
 template <typename T, int D>
 __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(
     int64_t n_x, int64_t n_z, const T *__restrict__ x, const T *__restrict__ z,
@@ -21,7 +44,7 @@ __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(
     T *__restrict__ K, int64_t ldk, int64_t strideK, int vec_ok) {
   const int b = blockIdx.z;
   const T var = var_p[b];
-  const T ls = ls_p[b];
+  const T inv_ls = T(1) / ls_p[b];
   T *Kb = K + (int64_t)b * strideK;
   const int64_t j0 = ((int64_t)blockIdx.x * GRAM_TX + threadIdx.x) * 4;
   const int64_t i0 = (int64_t)blockIdx.y * GRAM_ROWS;
@@ -51,17 +74,23 @@ __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(
         const T dlt = xi[e] - zc[c][e];
         s += dlt * dlt;
       }
-      const T dist = dsqrt<T>(s);  // jnp.linalg.norm(..., ord=2, axis=2)   gp.py:74
-      const T q = dist / ls;       // deltaX/ls                            gp.py:75
-      T k = var * dexp<T>(T(-0.5) * (q * q));
+      T k = var * GramMath<T>::expq(s, inv_ls);  // norm -> /ls -> square -> exp   gp.py:74-77
       if (add_jitter && (i == j0 + c)) k += jitter;  // k += jitter*eye     gp.py:79-80
       out[c] = k;
     }
     T *dst = Kb + i * ldk + j0;
     if (full) {
-      typename Vec4<T>::type v;
-      v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
-      *reinterpret_cast<typename Vec4<T>::type *>(dst) = v;
+      if constexpr (sizeof(T) == 4) {
+        // streaming store: the matrix is far larger than L2 and is read next by another launch
+        // (4.4 -> 5.9 TB/s; the f64 kernel is bound by its exp / sqrt and got slower with it)
+        typedef float vec4_t __attribute__((ext_vector_type(4)));
+        vec4_t v = {out[0], out[1], out[2], out[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<vec4_t *>(dst));
+      } else {
+        typename Vec4<T>::type v;
+        v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+        *reinterpret_cast<typename Vec4<T>::type *>(dst) = v;
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
