@@ -255,7 +255,11 @@ def test_draw_full_size_covariance(ops):
 def test_randn(ops, golden, ndt, tdt, tol):
     want = golden["randn_f64" if ndt == np.float64 else "randn_f32"]
     got = ops.randn((37,), tdt, DEV, seed=123456789012345, stream_id=9).cpu().numpy()
-    assert np.abs(got - want).max() < (1e-13 if ndt == np.float64 else 2e-6)
+    # f32 normals come from the hardware log2 / sqrt / sin / cos instructions: |error| <= 3e-5 at |z| ~ 5
+    assert np.abs(got - want).max() < (1e-13 if ndt == np.float64 else 5e-5)
+    if ndt == np.float32:
+        big = ops.randn((1 << 20,), tdt, DEV, seed=7, stream_id=3).cpu().numpy().astype(np.float64)
+        assert np.abs(big - orc.randn(1 << 20, seed=7, stream_id=3, dtype=np.float64)).max() < 5e-5
     z = ops.randn((1 << 20,), tdt, DEV, seed=1, stream_id=0)
     assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
     assert not torch.equal(z[:1000], ops.randn((1000,), tdt, DEV, seed=1, stream_id=1))
