@@ -176,6 +176,25 @@ def test_potrf_more_workgroups_than_cus(ops):
     assert err.max().item() < 2e-6, err.max().item()
 
 
+@pytest.mark.parametrize("batch", [1, 5, 8, 9, 13])
+def test_potrf_tile_map_batches(ops, batch):
+    """The trailing update is one 1-D launch whose workgroup ids are dealt to (XCD, matrix, tile):
+    batch sizes on both sides of the 8-matrix switch and not multiples of 8, with extra rows (their
+    tiles form the rectangle under the triangle), n = 3 outer blocks."""
+    rng = np.random.default_rng(21)
+    n, m = 700, 200
+    K = np.empty((batch, n, n)); X = rng.standard_normal((batch, m, n))
+    for b in range(batch):
+        g = rng.standard_normal((n, n + 16))
+        K[b] = g @ g.T / n + np.eye(n)
+    A, Xd = dev(K, torch.float64), dev(X, torch.float64)
+    info = ops.potrf_(A, Xd)
+    assert info.cpu().tolist() == [0] * batch
+    for b in range(batch):
+        L = np.linalg.cholesky(K[b])
+        assert rel(A[b], L) < 1e-12 and rel(Xd[b], orc.right_solve_lt(L, X[b])) < 1e-11
+
+
 def test_potrf_near_rank_one(ops):
     """Long lengthscales (the heavy tail of the training prior InverseGamma(1, .1), vae.py:157) make
     K ~ var 11^T + jitter I.  fp32 LAPACK factors these; so must the HIP path, with a backward error
