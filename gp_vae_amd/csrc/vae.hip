@@ -58,12 +58,17 @@ constexpr int GBM = 128, GBN = 64;
 template <typename T> struct GemmK { static constexpr int BK = TileK<T>::BK; };
 
 // KVEC: the K-contiguous operands (AKC / BKC) are 16-byte aligned row by row
-template <typename T, bool AKC, bool BKC, int EPI, bool KVEC>
+// BM: rows per workgroup tile, 128 (4 waves stacked, each 32 x 64) or 64 (2 x 2 waves, each 32 x 32) —
+// the latter for outputs of at most 64 rows ([dV3; dc3] is 51 x n: on 128-row tiles 60 % of its MFMA
+// time multiplied padding, and that time was what bound the launch).
+template <typename T, bool AKC, bool BKC, int EPI, bool KVEC, int BM = 128>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   using M = Mfma<T>;
   constexpr int GBK = GemmK<T>::BK;
-  constexpr int FM = 32 / M::TM;  // wave tile 32 x 64
-  constexpr int FN = 64 / M::TM;
+  constexpr int GBM = BM;             // shadows the namespace constant below this line
+  constexpr int WN = BM == 128 ? 1 : 2;  // waves along N
+  constexpr int FM = 32 / M::TM;         // wave tile 32 x (64 / WN)
+  constexpr int FN = 64 / WN / M::TM;
   // row-major image [rows][GBK + pad] for a K-contiguous operand, k-major [GBK][rows + pad] otherwise
   constexpr int LDA = AKC ? GBK + RmPad<T>::V : GBM + LdsPad<T>::V;
   constexpr int LDB = BKC ? GBK + RmPad<T>::V : GBN + LdsPad<T>::V;
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   __shared__ __align__(16) T Bs[BKC ? GBN * LDB : GBK * LDB];
   __shared__ T red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * 32, wn = (wave % WN) * (64 / WN);  // the wave's corner inside the tile
   const int64_t m0 = (int64_t)blockIdx.x * GBM, n0 = (int64_t)blockIdx.y * GBN;
   const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
   const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
           if constexpr (BKC) lbk.template store_fast<LDB>(Bs, tid);
           else lbm.template store_fast<LDB>(Bs, tid);
         },
-        [&]() { mma_ktile<T, FM, FN, GBK, AKC, LDA, BKC, LDB>(As, Bs, wave * 32, 0, lane, acc); });
+        [&]() { mma_ktile<T, FM, FN, GBK, AKC, LDA, BKC, LDB>(As, Bs, wm, wn, lane, acc); });
   }
 
   T lsum = T(0);
@@ -143,13 +149,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
                         TileIO<T>::usable(g.ldc, 32) && (EPI != EPI_DF || TileIO<T>::usable(g.ldy, 32));
   if (interior) {
     TileIO<T> ioc, ioy;
-    const int64_t rw = m0 + wave * 32;
-    ioc.init(g.C + rw * g.ldc + n0, g.ldc, lane);
-    if constexpr (EPI == EPI_DF) ioy.init(g.Yref + rw * g.ldy + n0, g.ldy, lane);
+    const int64_t rw = m0 + wm;
+    ioc.init(g.C + rw * g.ldc + n0 + wn, g.ldc, lane);
+    if constexpr (EPI == EPI_DF) ioy.init(g.Yref + rw * g.ldy + n0 + wn, g.ldy, lane);
     T bias[FN];
     if constexpr (EPI == EPI_BIAS || EPI == EPI_DF) {
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) bias[fn] = g.bias[n0 + fn * M::TM + M::col(lane)];
+      for (int fn = 0; fn < FN; ++fn) bias[fn] = g.bias[n0 + wn + fn * M::TM + M::col(lane)];
     }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
@@ -181,10 +187,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
     for (int r = 0; r < M::NACC; ++r) {
-      const int64_t row = m0 + wave * 32 + fm * M::TM + M::row(lane, r);
+      const int64_t row = m0 + wm + fm * M::TM + M::row(lane, r);
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn) {
-        const int64_t col = n0 + fn * M::TM + M::col(lane);
+        const int64_t col = n0 + wn + fn * M::TM + M::col(lane);
         const bool in = row < Mrows && col < g.N;
         const T v = acc[fm][fn][r];
         const int64_t ci = g.trans_c ? col * g.ldc + row : row * g.ldc + col;
@@ -221,8 +227,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
   }
 }
 
-template <typename T, bool AKC, bool BKC, int EPI>
+template <typename T, bool AKC, bool BKC, int EPI, int BM = 128>
 static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
+  constexpr int GBM = BM;
   if (g.M <= 0 || g.N <= 0) return;
   if (splitk < 1) splitk = 1;
   constexpr int GBK = GemmK<T>::BK;
@@ -233,9 +240,9 @@ static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
   dim3 grid((unsigned)cdiv(g.M, GBM), (unsigned)cdiv(g.N, GBN), (unsigned)nz);
   const bool kvec = (!AKC || g.vec_a) && (!BKC || g.vec_b);
   if (kvec || (!AKC && !BKC))
-    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, true>), grid, dim3(NTHREADS), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, true, BM>), grid, dim3(NTHREADS), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, false>), grid, dim3(NTHREADS), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, false, BM>), grid, dim3(NTHREADS), 0, st, g);
 }
 
 template <typename T> static inline bool mc_vec_ok(const void *base, int64_t ld) {
@@ -676,7 +683,7 @@ __global__ void adam_kernel(int64_t count, T *p, const T *g, T *m, T *v, T lr, T
 // more, shorter slices pay more prologue and atomics than they gain in memory parallelism.  With more
 // than 512 tiles' worth of work per slice the count is rounded to fill whole rounds of 512: 320 tiles
 // (the scaled MLP's dV3) would otherwise leave a quarter of the CUs with twice the work of the rest.
-static inline int pick_splitk(int64_t tiles, int64_t K) {
+static inline int pick_splitk(int64_t tiles, int64_t K, int64_t round = 512) {
   if (tiles < 1) tiles = 1;
   int64_t maxs = cdiv(K, 4 * 32);  // at least 4 (f32) k-tiles per slice
   if (maxs < 1) maxs = 1;
@@ -685,9 +692,9 @@ static inline int pick_splitk(int64_t tiles, int64_t K) {
   double best_eff = 0;
   for (int s = 1; s <= maxs; ++s) {
     const int64_t wgs = tiles * s;
-    const double eff = (double)wgs / (double)(cdiv(wgs, 512) * 512);
+    const double eff = (double)wgs / (double)(cdiv(wgs, round) * round);
     if (eff > best_eff + 0.05) { best_eff = eff; best = s; }  // the smallest s within 5 % of the best
-    if (wgs >= 4 * 512) break;
+    if (wgs >= 4 * round) break;
   }
   return best;
 }
@@ -768,7 +775,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
     g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.H1; g.ldc = h0;
     g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
     g.vec_a = kc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(P.W1, h0);
-    launch_gemm<T, true, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
+    launch_gemm<T, true, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
   }
   if (!wide) {
     GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_fwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm_f,
@@ -801,14 +808,17 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
       g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
       g.M = h0 + 1; g.N = n; g.K = B; g.a_ones_row = h0;
       g.vec_a = mc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(W.DF, n);
-      launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
+      if (h0 + 1 <= 64)
+        launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n, GBN), B));
+      else
+        launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
     }
     {  // dD2 += DF V3^T
       GemmArgs<T> g{};
       g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.dD2; g.ldc = h0;
       g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
       g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
-      launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(B, GBM) * cdiv(h0, GBN), n));
+      launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
     }
     if (!wide) {
       const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);
@@ -839,7 +849,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
       g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = (T *)G.W1; g.ldc = h0;
       g.M = n + 1; g.N = h0; g.K = B; g.a_ones_row = n;
       g.vec_a = mc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(W.dA1, h0);
-      launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(n + 1, GBM) * cdiv(h0, GBN), B));
+      launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n + 1, 64) * cdiv(h0, GBN), B, 1024));
     }
   }
   GPVAE_CHECK_LAUNCH("gpvae_vae_elbo");
