@@ -28,6 +28,7 @@ SIGNATURES = {
     "gpvae_gram_agg": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _d, _vp, _i64]),
     "gpvae_potrf_workspace_bytes": (_i64, [_i, _i64, _i64, _i]),
     "gpvae_potrf": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i, _vp]),
+    "gpvae_trsm": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64]),
     "gpvae_draw": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64,
                         _vp, _i64]),
     "gpvae_randn": (_i, [_vp, _i, _i64, _u64, _u64, _vp]),

@@ -1,0 +1,131 @@
+// trsm.hip — stand-alone triangular solve against an existing Cholesky factor (SURVEY.md §8b's export
+// list; rows a9 / a10).
+//
+// The hot paths never need it: every solve of the kriging / MVN paths rides the factorisation's
+// panel sweep as extra rows of gpvae_potrf (one pass over L).  This entry point is for callers that
+// KEEP a factor and meet new right-hand sides later — the reference's posterior code re-uses
+// `jnp.linalg.inv(k_xx + sigma I)` (src/model/inference.py:450-455) for `k_px` and `y` alike.
+//
+//   trans = 1:  X <- X L^-T   (every row x of X becomes the y with L y = x:   forward substitution)
+//   trans = 0:  X <- X L^-1   (every row x of X becomes the y with L^T y = x: backward substitution)
+// so X L^-T L^-1 = X A^-1 for A = L L^T.  Blocked by 64 columns: the columns already solved update
+// the current block through the generic tile product (MFMA, split over K, partial sums subtracted
+// with atomics), then each row finishes its 64 unknowns against the diagonal block held in LDS.
+// The update is "sum the products, subtract from C" — fine for a solve against a given factor (the
+// ordering that matters on nearly singular matrices is the factorisation's, potrf.hip).
+#include "gemm_tile.hpp"
+
+namespace gpvae {
+
+constexpr int TSB = 64;  // column block
+
+// k slices so that a launch has about 512 workgroups, at least 4 k-tiles each
+static inline int pick_splitk(int64_t tiles, int64_t K) {
+  int64_t s = 512 / (tiles > 0 ? tiles : 1);
+  const int64_t maxs = cdiv(K, 4 * 32);
+  if (s > maxs) s = maxs;
+  return (int)(s < 1 ? 1 : s);
+}
+
+// rows [row0, row0+256) of X, columns [c0, c0+w): finish the solve against the diagonal block of L
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(NTHREADS) void trsm_diag_kernel(int64_t m, int w, const T *__restrict__ Ld,
+                                                             int64_t ldl, T *X, int64_t ldx) {
+  __shared__ T Ls[TSB][TSB + 1];
+  __shared__ T rd[TSB];  // reciprocals of the diagonal
+  // Both variants run the SAME sweep, y_c = (x_c - sum_{k>c} y_k U[c][k]) / U[c][c], c descending:
+  // backward substitution has U = L^T; forward substitution L y = x is that sweep on the index-reversed
+  // problem (U = P L P, P = reversal).  (The ascending loop written directly made the compiler keep
+  // every partial sum and every L entry live: 512 registers + 6.5 KB of scratch, 240 us a launch.)
+  // Image: Ls[k][c] = U[c][k];  columns / rows >= w are an identity block.
+  constexpr int R = TSB - 1;
+  for (int idx = threadIdx.x; idx < TSB * TSB; idx += NTHREADS) {
+    const int i = idx / TSB, j = idx % TSB;  // L[i][j]
+    const T v = (i < w && j <= i) ? Ld[(int64_t)i * ldl + j] : (i == j ? T(1) : T(0));
+    if (TRANS) Ls[R - j][R - i] = v;
+    else Ls[i][j] = v;
+  }
+  if (threadIdx.x < TSB) {
+    const int d = TRANS ? R - (int)threadIdx.x : (int)threadIdx.x;
+    rd[threadIdx.x] = d < w ? T(1) / Ld[(int64_t)d * ldl + d] : T(1);
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * NTHREADS + threadIdx.x;
+  if (r >= m) return;
+  T *xr = X + r * ldx;
+  T x[TSB];
+#pragma unroll
+  for (int c = 0; c < TSB; ++c) {
+    const int s = TRANS ? R - c : c;
+    x[c] = s < w ? xr[s] : T(0);
+  }
+#pragma unroll
+  for (int c = TSB - 1; c >= 0; --c) {
+    T a = x[c];
+#pragma unroll
+    for (int k = c + 1; k < TSB; ++k) a -= x[k] * Ls[k][c];
+    x[c] = a * rd[c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < TSB; ++c) {
+    const int s = TRANS ? R - c : c;
+    if (s < w) xr[s] = x[c];
+  }
+}
+
+template <typename T>
+static int run_trsm(hipStream_t st, int trans, int64_t n, int64_t m, const void *L_v, int64_t ldl,
+                    void *X_v, int64_t ldx) {
+  const T *L = (const T *)L_v;
+  T *X = (T *)X_v;
+  const int64_t nb = cdiv(n, TSB);
+  const unsigned dgrid = (unsigned)cdiv(m, NTHREADS);
+  for (int64_t jb = 0; jb < nb; ++jb) {
+    const int64_t j = trans ? jb : nb - 1 - jb;  // forward / backward over the column blocks
+    const int64_t c0 = j * TSB;
+    const int w = (int)((c0 + TSB <= n) ? TSB : n - c0);
+    GemmArgs<T> g{};
+    g.C = X + c0; g.ldc = ldx; g.M = m; g.N = w; g.negate = 1;  // partial sums subtracted by atomics
+    g.a_ones_row = -1; g.b_ones_row = -1;
+    if (trans && c0 > 0) {
+      // X[:, c0:c0+w] -= X[:, :c0] L[c0:c0+w, :c0]^T      (both operands K-contiguous)
+      g.A = X; g.lda = ldx; g.B = L + c0 * ldl; g.ldb = ldl; g.K = c0;
+      g.vec_a = kc_vec_ok<T>(X, ldx); g.vec_b = kc_vec_ok<T>(g.B, ldl);
+      launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(m, 64), g.K));
+    } else if (!trans && c0 + w < n) {
+      // X[:, c0:c0+w] -= X[:, c0+w:] L[c0+w:, c0:c0+w]    (B is N-contiguous)
+      g.A = X + c0 + w; g.lda = ldx; g.B = L + (c0 + w) * ldl + c0; g.ldb = ldl; g.K = n - c0 - w;
+      g.vec_a = kc_vec_ok<T>(g.A, ldx); g.vec_b = mc_vec_ok<T>(g.B, ldl);
+      launch_gemm<T, true, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(m, 64), g.K));
+    }
+    if (trans)
+      hipLaunchKernelGGL((trsm_diag_kernel<T, true>), dim3(dgrid), dim3(NTHREADS), 0, st, m, w,
+                         L + c0 * ldl + c0, ldl, X + c0, ldx);
+    else
+      hipLaunchKernelGGL((trsm_diag_kernel<T, false>), dim3(dgrid), dim3(NTHREADS), 0, st, m, w,
+                         L + c0 * ldl + c0, ldl, X + c0, ldx);
+  }
+  GPVAE_CHECK_LAUNCH("gpvae_trsm");
+  return 0;
+}
+
+}  // namespace gpvae
+
+using namespace gpvae;
+
+extern "C" int gpvae_trsm(void *stream, int dtype, int trans, int64_t n, int64_t m, const void *L,
+                          int64_t ldl, void *X, int64_t ldx) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_trsm: bad dtype %d", dtype);
+  GPVAE_REQUIRE(trans == 0 || trans == 1, 3, "gpvae_trsm: trans must be 0 or 1");
+  GPVAE_REQUIRE(n >= 0, 4, "gpvae_trsm: n < 0");
+  GPVAE_REQUIRE(m >= 0, 5, "gpvae_trsm: m < 0");
+  if (n == 0 || m == 0) return 0;
+  GPVAE_REQUIRE(L, 6, "gpvae_trsm: L is NULL");
+  GPVAE_REQUIRE(ldl >= n, 7, "gpvae_trsm: ldl < n");
+  GPVAE_REQUIRE(X, 8, "gpvae_trsm: X is NULL");
+  GPVAE_REQUIRE(ldx >= n, 9, "gpvae_trsm: ldx < n");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32 ? run_trsm<float>(st, trans, n, m, L, ldl, X, ldx)
+                            : run_trsm<double>(st, trans, n, m, L, ldl, X, ldx);
+}

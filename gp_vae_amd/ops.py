@@ -125,6 +125,22 @@ def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None):
     return info
 
 
+def trsm_(L, X, trans=True):
+    """In place X <- X L^-T (trans, every row x becomes the y with L y = x) or X <- X L^-1 (every row
+    becomes the y with L^T y = x) against an existing lower factor L [n,n]; X [m,n].  Both in turn give
+    X A^-1 for A = L L^T.  The hot paths do not need this (their solves ride gpvae_potrf's extra rows)."""
+    _dev(L, X)
+    n = L.shape[0]
+    if L.dim() != 2 or L.shape != (n, n) or X.dim() != 2 or X.shape[1] != n or L.stride(1) != 1 or X.stride(1) != 1:
+        raise GpvaeError("trsm_: L must be [n,n], X [m,n], unit column strides")
+    if X.dtype != L.dtype:
+        raise GpvaeError("trsm_: dtype mismatch")
+    lib = _lib.load()
+    check(lib.gpvae_trsm(_stream(), _dt(L), 1 if trans else 0, n, X.shape[0], _p(L), L.stride(0) if n > 0 else 1,
+                         _p(X), X.stride(0) if X.shape[0] > 0 else max(n, 1)), "gpvae_trsm")
+    return X
+
+
 def draw(L, E, E2=None, sigma=None, want_f=False):
     """Y = E L^T (+ sigma*E2).  L [n,n] lower factor, E/E2 [nb,n].  Returns Y or (F, Y)."""
     _dev(L, E, E2)

@@ -80,6 +80,16 @@ int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t 
                 int64_t strideA, int64_t m_extra, void *X, int64_t ldx, int64_t strideX,
                 int32_t *info, int flags, void *work);
 
+/* ---- a9/a10: stand-alone triangular solve against an existing factor ----------------------------
+ * The hot paths do not call it: every solve of gp_prediction and of the MVN potential rides
+ * gpvae_potrf's extra rows.  For callers that keep L and meet new right-hand sides later, as the
+ * reference re-uses jnp.linalg.inv(k_xx + sigma I) for k_px and y (inference.py:450-455).
+ * L: [n, ldl] lower factor (strict upper part not referenced); X: [m, ldx], in place:
+ *   trans = 1:  X <- X L^-T   (row x -> y with L y = x);     trans = 0:  X <- X L^-1   (L^T y = x);
+ * both in turn: X A^-1 with A = L L^T.  Bound: MFMA (m n^2 flop per call).                        */
+int gpvae_trsm(void *stream, int dtype, int trans, int64_t n, int64_t m, const void *L, int64_t ldl,
+               void *X, int64_t ldx);
+
 /* ---- a3/a4: MVN draws ---------------------------------------------------------------------------
  * Replaces f = L eps; y = f + sigma*eps' of GP.sample under Predictive (gp.py:190-194,
  * vae.py:160-162,223-226): for nb draws sharing one factor,

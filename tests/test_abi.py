@@ -20,7 +20,7 @@ def header_symbols():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = header_symbols()
-    assert len(names) == 21
+    assert len(names) == 22
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
@@ -52,6 +52,9 @@ def test_argument_validation_without_a_gpu():
     assert lib.gpvae_gram_se(null, 0, 1, 0, 4, null, null, 1, null, null, 0.0, null, 4, 0) == 0
     assert lib.gpvae_potrf(null, 0, 0, 1, null, 0, 0, 0, null, 0, 0, null, 0, null) == 0
     assert lib.gpvae_draw(null, 0, 0, 4, null, 0, null, 0, null, 0, null, null, 0, null, 0) == 0
+    assert lib.gpvae_trsm(null, 0, 2, 8, 4, null, 8, null, 8) == -3   # trans not 0/1
+    assert lib.gpvae_trsm(null, 0, 1, 8, 4, null, 8, null, 8) == -6   # L is NULL
+    assert lib.gpvae_trsm(null, 0, 1, 0, 4, null, 0, null, 0) == 0    # empty problem
 
 
 def test_size_queries():

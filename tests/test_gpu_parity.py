@@ -284,6 +284,31 @@ def test_randn(ops, golden, ndt, tdt, tol):
     assert not torch.equal(z[:1000], ops.randn((1000,), tdt, DEV, seed=1, stream_id=1))
 
 
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_trsm_against_existing_factor(ops, ndt, tdt, tol):
+    """gpvae_trsm: X L^-T and X L^-1 against scipy.linalg.solve_triangular, ragged n (not a multiple of
+    the 64-column block), padded leading dimensions, more rows than one workgroup; both in turn = X A^-1."""
+    import scipy.linalg
+    rng = np.random.default_rng(31)
+    for n, m in ((1, 3), (50, 7), (64, 300), (333, 515), (1000, 260)):
+        g = rng.standard_normal((n, n + 8))
+        A = g @ g.T / n + np.eye(n)
+        L = np.linalg.cholesky(A)
+        X = rng.standard_normal((m, n))
+        Lb = torch.zeros((n, n + 3), dtype=tdt, device=DEV); Lb[:, :n] = dev(L, tdt)
+        Lb[:, :n] += torch.triu(torch.full((n, n), 7.0, dtype=tdt, device=DEV), 1)  # junk above the diagonal
+        t = 1e-10 if ndt == np.float64 else 2e-4
+        Xb = torch.zeros((m, n + 5), dtype=tdt, device=DEV); Xb[:, :n] = dev(X, tdt)
+        ops.trsm_(Lb[:, :n], Xb[:, :n], trans=True)
+        want = scipy.linalg.solve_triangular(L, X.T, lower=True).T
+        assert rel(Xb[:, :n], want) < t and torch.all(Xb[:, n:] == 0)
+        ops.trsm_(Lb[:, :n], Xb[:, :n], trans=False)
+        assert rel(Xb[:, :n], np.linalg.solve(A, X.T).T) < 20 * t
+        Xc = dev(X, tdt)
+        ops.trsm_(Lb[:, :n], Xc, trans=False)
+        assert rel(Xc, scipy.linalg.solve_triangular(L, X.T, lower=True, trans="T").T) < t
+
+
 # ---- a9 kriging ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
 def test_kriging(ops, golden, ndt, tdt, tol):

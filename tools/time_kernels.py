@@ -32,3 +32,15 @@ for batch in (1, 16, 32, 64):
         A.copy_(K)
     t = timeit(f, 5) - timeit(c, 5)
     print(f"potrf batch {batch} n {n}: {t:.3f} ms  {batch*n**3/3/t/1e9:.1f} TF")
+
+# stand-alone solve against an existing factor (not on the hot paths)
+A = ops.gram_se(X, X, 1.0, 0.3, jitter=1e-3); A.diagonal().add_(0.1)
+ops.potrf_(A)
+Xr = ops.randn((4096, n), seed=5); Xw = Xr.clone()
+for tr in (True, False):
+    def g():
+        Xw.copy_(Xr); ops.trsm_(A, Xw, trans=tr)
+    def c2():
+        Xw.copy_(Xr)
+    t = timeit(g, 5) - timeit(c2, 5)
+    print(f"trsm trans={int(tr)} n {n} m 4096: {t:.3f} ms  {4096*n*n/t/1e9:.1f} TF")
