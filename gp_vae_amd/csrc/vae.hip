@@ -9,7 +9,8 @@
 //   decoder(params, z)         src/model/inference.py:246
 //
 // Structure of one ELBO evaluation (B samples of length n; h0,h1,z small):
-//   [n-sized products on MFMA, split over K where the output is small, partial sums by float atomics]
+//   [n-sized products on MFMA, split over K where the output is small, partial sums by float atomics;
+//    f32 training calls with whole tiles run DF / dV3|dc3 / dD2 as ONE kernel, vae_out_fused_kernel]
 //     A1  += Y  W1                 (B x h0, K = n)          gemm<KC,MC>   reads Y once
 //     DF   = (D2 V3 + c3 - Y)/s^2  (B x n,  K = h0)         gemm<KC,MC>   + the data term of the loss
 //     dV3|dc3 += [D2|1]^T DF       ((h0+1) x n, K = B)      gemm<MC,MC>
@@ -439,6 +440,121 @@ static inline unsigned ew_blocks(int64_t count) {
   return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// ---- decoder output layer, forward and backward in one pass (f32, h0 + 1 <= 64) ---------------------
+// The three n-sized products of the decoder's last layer share their operands:
+//   F   = [D2 | 1] [V3; c3]                     DF = (F - Y) / sigma^2 ,  loss += 0.5 sum (F - Y)^2 / sigma^2
+//   dD2 += DF V3^T                              (per 64-column tile: K = the tile's columns)
+//   [dV3; dc3] += [D2 | 1]^T DF                 (per 128-row block: K = the block's rows)
+// As separate launches DF (B x n) is written once and read twice (3 x 67 MB at C3).  Here a workgroup
+// keeps its 128 rows of [D2 | 1] in LDS and walks `nt` column tiles: product 1 from LDS, the
+// epilogue leaves the DF tile in LDS, and that tile is the A operand of product 2 (row-major image)
+// and the B operand of product 3 (k-major image) as it lies; the V3 tile is product 1's k-major B
+// image and, read the other way, product 2's row-major B image.  DF never goes to HBM; dD2 stays in
+// registers over the walk.  Y is read once, V3 once per row block (L2).
+constexpr int FS = 68;  // LDS row stride of the 64-wide images (16-byte aligned rows)
+
+__global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
+    int64_t n, int h0, const float *__restrict__ D2, const float *__restrict__ V3c,
+    const float *__restrict__ Y, int64_t ldy, float inv_var, float *loss, float *dD2, float *dV3c,
+    int nt) {
+  using M = Mfma<float>;
+  __shared__ __align__(16) float D2s[128 * FS];  // [row][k]: D2, a ones column at k = h0, zeros beyond
+  __shared__ __align__(16) float V3s[64 * FS];   // [k][col]: V3 rows, c3 at k = h0, zeros beyond
+  __shared__ __align__(16) float DFs[128 * FS];  // [row][col]
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 128;
+  const int64_t tile0 = (int64_t)blockIdx.y * nt;
+  const int64_t ntiles = n / 64;
+
+  for (int idx = tid; idx < 128 * 64; idx += NTHREADS) {
+    const int r = idx >> 6, k = idx & 63;
+    D2s[r * FS + k] = k < h0 ? D2[(row0 + r) * h0 + k] : (k == h0 ? 1.0f : 0.0f);
+  }
+  // V3 tile: 64 k-rows x 16 vectors, 4 per thread; rows past h0 lie outside the buffer and read 0
+  i32x4_t vrs = make_buffer_rsrc(V3c);
+  vrs[2] = __builtin_amdgcn_readfirstlane((int)((int64_t)(h0 + 1) * n * 4));
+  int vvo[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int v = tid + p * NTHREADS;
+    vvo[p] = (v >> 4) * (int)(n * 4) + (v & 15) * 16;
+  }
+  i32x4_t vreg[4];
+  auto load_v3 = [&](int64_t tile) {
+    const int so = (int)(tile * 64 * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vreg[p] = raw_buffer_load_b128(vrs, vvo[p], so, 0);
+  };
+  load_v3(tile0);
+  // data tile of this wave's 32 rows; like the V3 tile it is requested one tile ahead and BEFORE the
+  // tile's atomics: loads return in order, a load issued behind 16 float atomics would not be
+  // counted done until they have all been (about 3 k cycles with every CU adding at once)
+  float yv[2][M::NACC];
+  auto load_y = [&](int64_t tile) {
+    TileIO<float> ioy;
+    ioy.init(Y + (row0 + wave * 32) * ldy + tile * 64, ldy, lane);
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) yv[fn][r] = ioy.load(0, fn, r);
+  };
+  load_y(tile0);
+
+  typename M::acc_t acc2[1][2];  // dD2 rows of this wave x (h0 padded to 64), over the whole walk
+  zero_acc<float, 1, 2>(acc2);
+  float lsum = 0.0f;
+  const int wm3 = (wave >> 1) * 32, wn3 = (wave & 1) * 32;  // product 3: (h0 index, column) quadrant
+
+  for (int t = 0; t < nt && tile0 + t < ntiles; ++t) {
+    const int64_t col0 = (tile0 + t) * 64;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int v = tid + p * NTHREADS;
+      *reinterpret_cast<i32x4_t *>(&V3s[(v >> 4) * FS + (v & 15) * 4]) = vreg[p];
+    }
+    __syncthreads();  // V3s (and, first time round, D2s) staged
+
+    typename M::acc_t acc1[1][2];
+    zero_acc<float, 1, 2>(acc1);
+    mma_ktile<float, 1, 2, 64, true, FS, false, FS>(D2s, V3s, wave * 32, 0, lane, acc1);
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const float diff = acc1[0][fn][r] - yv[fn][r];
+        lsum += diff * diff;
+        DFs[(wave * 32 + M::row(lane, r)) * FS + fn * 32 + M::col(lane)] = diff * inv_var;
+      }
+    if (t + 1 < nt && tile0 + t + 1 < ntiles) {  // next tile's operands, ahead of this tile's atomics
+      load_y(tile0 + t + 1);
+      load_v3(tile0 + t + 1);
+    }
+    __syncthreads();  // DF tile complete
+    mma_ktile<float, 1, 2, 64, true, FS, true, FS>(DFs, V3s, wave * 32, 0, lane, acc2);  // dD2 += DF V3^T
+    typename M::acc_t acc3[1][1];  // [dV3; dc3] tile: K = the 128 rows
+    zero_acc<float, 1, 1>(acc3);
+    mma_ktile<float, 1, 1, 128, false, FS, false, FS>(D2s, DFs, wm3, wn3, lane, acc3);
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      const int hi = wm3 + M::row(lane, r);
+      if (hi <= h0) atomicAdd(&dV3c[(int64_t)hi * n + col0 + wn3 + M::col(lane)], acc3[0][0][r]);
+    }
+    __syncthreads();  // V3s / DFs may be overwritten
+  }
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int r = 0; r < M::NACC; ++r) {
+      const int hi = fn * 32 + M::col(lane);
+      if (hi < h0) atomicAdd(&dD2[(row0 + wave * 32 + M::row(lane, r)) * h0 + hi], acc2[0][fn][r]);
+    }
+  lsum = wave_sum<float>(lsum);
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (tid == 0) atomicAdd(loss, 0.5f * inv_var * (red[0] + red[1] + red[2] + red[3]));
+}
+
 // ---- Adam (jax.experimental.optimizers.adam, as numpyro.optim.Adam wraps it) ------------------------
 //   m = (1-b1) g + b1 m ; v = (1-b2) g^2 + b2 v ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
 template <typename T>
@@ -569,7 +685,23 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
     dense_gemm<T>(st, W.Z, B, z, P.V1, h1, P.c1, 1, W.D1);
     dense_gemm<T>(st, W.D1, B, h1, P.V2, h0, P.c2, 1, W.D2);
   }
-  {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
+  // f32 with gradients, whole tiles: the output layer's three n-sized products in one pass
+  bool fused = false;
+  if constexpr (sizeof(T) == 4) {
+    fused = grads != nullptr && h0 + 1 <= 64 && B % 128 == 0 && n % 64 == 0 &&
+            (int64_t)(h0 + 1) * n * 4 < ((int64_t)1 << 31) && 32 * ldy * 4 < ((int64_t)1 << 31);
+  }
+  if (grads != nullptr) (void)hipMemsetAsync(grads, 0, sizeof(T) * vae_param_count(n, h0, h1, z), st);
+  if (fused) {
+    if constexpr (sizeof(T) == 4) {
+      VaeParams<T> G(grads, n, h0, h1, z);
+      const int64_t rb128 = B / 128, ntiles = n / 64;
+      int nt = (int)(rb128 * ntiles / 256);  // about 256 workgroups: one per CU (87 KB of LDS each) in one round
+      if (nt < 1) nt = 1;
+      hipLaunchKernelGGL(vae_out_fused_kernel, dim3((unsigned)rb128, (unsigned)cdiv(ntiles, nt)), dim3(NTHREADS),
+                         0, st, n, h0, W.D2, P.V3, Y, ldy, inv_var, loss, W.dD2, (T *)G.V3, nt);
+    }
+  } else {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
     GemmArgs<T> g{};
     g.A = W.D2; g.lda = h0; g.B = P.V3; g.ldb = n; g.C = W.DF; g.ldc = n;
     g.M = B; g.N = n; g.K = h0; g.a_ones_row = -1;
@@ -579,23 +711,24 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   }
   if (grads != nullptr) {
     VaeParams<T> G(grads, n, h0, h1, z);
-    (void)hipMemsetAsync(grads, 0, sizeof(T) * vae_param_count(n, h0, h1, z), st);
-    {  // [dV3; dc3] += [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
-      GemmArgs<T> g{};
-      g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
-      g.M = h0 + 1; g.N = n; g.K = B; g.a_ones_row = h0;
-      g.vec_a = mc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(W.DF, n);
-      if (h0 + 1 <= 64)
-        launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n, GBN), B));
-      else
-        launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
-    }
-    {  // dD2 += DF V3^T
-      GemmArgs<T> g{};
-      g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.dD2; g.ldc = h0;
-      g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
-      g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
-      launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+    if (!fused) {
+      {  // [dV3; dc3] += [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
+        GemmArgs<T> g{};
+        g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
+        g.M = h0 + 1; g.N = n; g.K = B; g.a_ones_row = h0;
+        g.vec_a = mc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(W.DF, n);
+        if (h0 + 1 <= 64)
+          launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n, GBN), B));
+        else
+          launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
+      }
+      {  // dD2 += DF V3^T
+        GemmArgs<T> g{};
+        g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.dD2; g.ldc = h0;
+        g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
+        g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
+        launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+      }
     }
     if (!wide) {
       const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);

@@ -534,6 +534,27 @@ def test_vae_wide_hidden_layers(ops, ndt, tdt, tol, dims):
     assert rel(ops.decoder_vjp(decp, dev(ez, tdt), dev(dF, tdt), h0, h1), orc.decoder_vjp(p, ez, dF)) < t
 
 
+@pytest.mark.parametrize("dims", [(256, 192, 63, 5, 3), (128, 64, 1, 2, 1), (384, 1024, 35, 30, 10), (128, 640, 50, 30, 15)])
+def test_vae_fused_output_layer(ops, dims):
+    """f32 with gradients, B % 128 == 0, n % 64 == 0, h0 + 1 <= 64: the decoder's output layer runs as
+    ONE kernel (forward product, data term, dD2 and [dV3; dc3]; vae_out_fused_kernel).  Widest and
+    narrowest h0, one and several column tiles per workgroup; loss + 14 gradient arrays vs the oracle,
+    and the evaluate-only call (separate kernels) must give the same loss."""
+    B, n, h0, h1, z = dims
+    rng = np.random.default_rng(17)
+    p = {k: (5 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+    lo, go = orc.elbo_loss_and_grads(p, Y, ez, 0.1)
+    flat = dev(orc.flatten(p), torch.float32)
+    grads = torch.empty_like(flat)
+    loss = ops.vae_elbo(flat, dev(Y, torch.float32), dev(ez, torch.float32), (h0, h1, z), 0.1, grads=grads)
+    loss_eval = ops.vae_elbo(flat, dev(Y, torch.float32), dev(ez, torch.float32), (h0, h1, z), 0.1)
+    assert abs(loss.item() - lo) < 1e-4 * abs(lo) and abs(loss.item() - loss_eval.item()) < 1e-5 * abs(lo)
+    gd = orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+    for k in orc.PARAM_NAMES:
+        assert rel(gd[k], go[k]) < 1e-4, k
+
+
 def test_vae_elbo_full_size_c3(ops):
     """The bench shape (B = n = 4096, 50-30-15, fp32) against the oracle: every fast path of the tile
     products (VALU-free k loops, ragged-K through the buffer range check, TileIO epilogues, split-K
