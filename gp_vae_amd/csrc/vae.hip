@@ -458,14 +458,20 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
     const float *__restrict__ Y, int64_t ldy, float inv_var, float *loss, float *dD2, float *dV3c,
     int nt) {
   using M = Mfma<float>;
-  __shared__ __align__(16) float D2s[128 * FS];  // [row][k]: D2, a ones column at k = h0, zeros beyond
-  __shared__ __align__(16) float V3s[64 * FS];   // [k][col]: V3 rows, c3 at k = h0, zeros beyond
-  __shared__ __align__(16) float DFs[128 * FS];  // [row][col]
-  __shared__ float red[4];
+  // 153 KB of LDS, one workgroup per CU.  The V3 image is triple- and the DF image double-buffered, so
+  // that ONE barrier per tile (DF tile complete / next V3 tile staged) orders everything and product 1
+  // of tile t+1 follows product 3 of tile t in each wave's MFMA stream:
+  //   V3s[(t+1) % 3] is written in tile t; its last readers (product 2 of tile t-2) finished before
+  //   the barrier of tile t-1, which every wave has passed; DFs[t & 1] likewise (readers: tile t-2).
+  __shared__ __align__(16) float lds[128 * FS + 3 * 64 * FS + 2 * 128 * FS];
+  float *D2s = lds;               // [row][k]: D2, a ones column at k = h0, zeros beyond
+  float *V3b = D2s + 128 * FS;    // 3 x [k][col]: V3 rows, c3 at k = h0, zeros beyond
+  float *DFb = V3b + 3 * 64 * FS; // 2 x [row][col]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * 128;
   const int64_t tile0 = (int64_t)blockIdx.y * nt;
   const int64_t ntiles = n / 64;
+  const int ntl = (int)((tile0 + nt <= ntiles) ? nt : ntiles - tile0);  // tiles of this workgroup (>= 1)
 
   for (int idx = tid; idx < 128 * 64; idx += NTHREADS) {
     const int r = idx >> 6, k = idx & 63;
@@ -486,10 +492,16 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
 #pragma unroll
     for (int p = 0; p < 4; ++p) vreg[p] = raw_buffer_load_b128(vrs, vvo[p], so, 0);
   };
-  load_v3(tile0);
-  // data tile of this wave's 32 rows; like the V3 tile it is requested one tile ahead and BEFORE the
-  // tile's atomics: loads return in order, a load issued behind 16 float atomics would not be
-  // counted done until they have all been (about 3 k cycles with every CU adding at once)
+  auto stage_v3 = [&](float *dst) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int v = tid + p * NTHREADS;
+      *reinterpret_cast<i32x4_t *>(&dst[(v >> 4) * FS + (v & 15) * 4]) = vreg[p];
+    }
+  };
+  // data tile of this wave's 32 rows; like the V3 tile it is requested ahead and BEFORE the previous
+  // tile's atomics: loads return in order, a load issued behind 16 float atomics would not be counted
+  // done until they have all been (about 3 k cycles with every CU adding at once)
   float yv[2][M::NACC];
   auto load_y = [&](int64_t tile) {
     TileIO<float> ioy;
@@ -499,22 +511,21 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
 #pragma unroll
       for (int r = 0; r < M::NACC; ++r) yv[fn][r] = ioy.load(0, fn, r);
   };
+  load_v3(tile0);
+  stage_v3(V3b);
   load_y(tile0);
+  if (ntl > 1) load_v3(tile0 + 1);
+  __syncthreads();  // D2s and the first V3 tile staged
 
   typename M::acc_t acc2[1][2];  // dD2 rows of this wave x (h0 padded to 64), over the whole walk
   zero_acc<float, 1, 2>(acc2);
   float lsum = 0.0f;
   const int wm3 = (wave >> 1) * 32, wn3 = (wave & 1) * 32;  // product 3: (h0 index, column) quadrant
 
-  for (int t = 0; t < nt && tile0 + t < ntiles; ++t) {
+  for (int t = 0; t < ntl; ++t) {
     const int64_t col0 = (tile0 + t) * 64;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int v = tid + p * NTHREADS;
-      *reinterpret_cast<i32x4_t *>(&V3s[(v >> 4) * FS + (v & 15) * 4]) = vreg[p];
-    }
-    __syncthreads();  // V3s (and, first time round, D2s) staged
-
+    const float *V3s = V3b + (t % 3) * 64 * FS;
+    float *DFs = DFb + (t & 1) * 128 * FS;
     typename M::acc_t acc1[1][2];
     zero_acc<float, 1, 2>(acc1);
     mma_ktile<float, 1, 2, 64, true, FS, false, FS>(D2s, V3s, wave * 32, 0, lane, acc1);
@@ -526,11 +537,12 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
         lsum += diff * diff;
         DFs[(wave * 32 + M::row(lane, r)) * FS + fn * 32 + M::col(lane)] = diff * inv_var;
       }
-    if (t + 1 < nt && tile0 + t + 1 < ntiles) {  // next tile's operands, ahead of this tile's atomics
+    if (t + 1 < ntl) {  // next tile's operands, ahead of this tile's atomics
+      stage_v3(V3b + ((t + 1) % 3) * 64 * FS);
       load_y(tile0 + t + 1);
-      load_v3(tile0 + t + 1);
+      if (t + 2 < ntl) load_v3(tile0 + t + 2);
     }
-    __syncthreads();  // DF tile complete
+    __syncthreads();  // DF tile complete, next V3 tile staged
     mma_ktile<float, 1, 2, 64, true, FS, true, FS>(DFs, V3s, wave * 32, 0, lane, acc2);  // dD2 += DF V3^T
     typename M::acc_t acc3[1][1];  // [dV3; dc3] tile: K = the 128 rows
     zero_acc<float, 1, 1>(acc3);
@@ -540,7 +552,6 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
       const int hi = wm3 + M::row(lane, r);
       if (hi <= h0) atomicAdd(&dV3c[(int64_t)hi * n + col0 + wn3 + M::col(lane)], acc3[0][0][r]);
     }
-    __syncthreads();  // V3s / DFs may be overwritten
   }
 #pragma unroll
   for (int fn = 0; fn < 2; ++fn)
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
       const int hi = fn * 32 + M::col(lane);
       if (hi < h0) atomicAdd(&dD2[(row0 + wave * 32 + M::row(lane, r)) * h0 + hi], acc2[0][fn][r]);
     }
+  __shared__ float red[4];
   lsum = wave_sum<float>(lsum);
   if (lane == 0) red[wave] = lsum;
   __syncthreads();
