@@ -8,18 +8,23 @@
 //   optim.Adam                 vae.py:212 (numpyro/jax Adam: b1 .9, b2 .999, eps 1e-8)
 //   decoder(params, z)         src/model/inference.py:246
 //
-// Structure of one ELBO evaluation (B samples of length n; h0,h1,z small):
-//   [n-sized products on MFMA, split over K where the output is small, partial sums by float atomics;
-//    f32 training calls with whole tiles run DF / dV3|dc3 / dD2 as ONE kernel, vae_out_fused_kernel]
+// Structure of one ELBO evaluation (B samples of length n):
+//   [n-sized products on MFMA (gemm_tile.hpp), split over K where the output is small, partial sums
+//    by float atomics]
 //     A1  += Y  W1                 (B x h0, K = n)          gemm<KC,MC>   reads Y once
 //     DF   = (D2 V3 + c3 - Y)/s^2  (B x n,  K = h0)         gemm<KC,MC>   + the data term of the loss
 //     dV3|dc3 += [D2|1]^T DF       ((h0+1) x n, K = B)      gemm<MC,MC>
 //     dD2 += DF V3^T               (B x h0, K = n)          gemm<KC,KC>
 //     dW1|db1 += [Y|1]^T dA1       ((n+1) x h0, K = B)      gemm<MC,MC>
-//   [everything between, per block of 16 samples, in LDS on the vector ALU]
-//     vae_mid_fwd: bias+relu, h0->h1->(mu, log sd), reparametrise, z->h1->h0; latent loss terms
-//     vae_mid_bwd: the same chain backwards; small weight gradients by atomics
-// Y is read three times (A1, DF, dW1) and DF twice; bound: HBM for the n-sized products.
+//    f32 training calls with whole tiles run DF / dV3|dc3 / dD2 as ONE kernel (vae_out_fused_kernel):
+//    DF then never goes to HBM and Y is read twice (A1, output layer) + once for dW1.
+//   [everything between]
+//     small hidden layers (the reference's 35-30-10 / 50-30-15; weights fit LDS): per block of 16
+//     samples in LDS on the vector ALU —
+//       vae_mid_fwd: bias+relu, h0->h1->(mu, log sd), reparametrise, z->h1->h0; latent loss terms
+//       vae_mid_bwd: the same chain backwards; weight gradients into 16 replicas (+ reduce kernel)
+//     wide hidden layers (up to 1024): every layer a tile product with a fused bias / relu / mask
+//     epilogue (EPI_FUSED) + four elementwise kernels.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
