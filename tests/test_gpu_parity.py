@@ -534,7 +534,8 @@ def test_vae_wide_hidden_layers(ops, ndt, tdt, tol, dims):
     assert rel(ops.decoder_vjp(decp, dev(ez, tdt), dev(dF, tdt), h0, h1), orc.decoder_vjp(p, ez, dF)) < t
 
 
-@pytest.mark.parametrize("dims", [(256, 192, 63, 5, 3), (128, 64, 1, 2, 1), (384, 1024, 35, 30, 10), (128, 640, 50, 30, 15)])
+@pytest.mark.parametrize("dims", [(256, 192, 63, 5, 3), (128, 64, 1, 2, 1), (384, 1024, 35, 30, 10), (128, 640, 50, 30, 15),
+                                  (4096, 1088, 50, 30, 15)])  # last: 2 column tiles per workgroup + a remainder
 def test_vae_fused_output_layer(ops, dims):
     """f32 with gradients, B % 128 == 0, n % 64 == 0, h0 + 1 <= 64: the decoder's output layer runs as
     ONE kernel (forward product, data term, dD2 and [dV3; dc3]; vae_out_fused_kernel).  Widest and
