@@ -107,7 +107,8 @@ class StepEngine():
         self.ezbuf = [torch.empty((B, self.z), dtype=dtype, device=dev) for _ in range(2)]
         self.grads = torch.empty(ops.vae_param_count(n, self.h0, self.h1, self.z), dtype=dtype,
                                  device=dev)
-        self.loss = torch.zeros(1, dtype=dtype, device=dev)
+        self.loss = torch.zeros(1, dtype=dtype, device=dev)        # the last step's loss
+        self.loss_steps = self.loss
         self.loss_sum = torch.zeros(1, dtype=dtype, device=dev)
         self.work = ops.VaeWorkspace(B, n, self.h0, self.h1, self.z, dtype, dev)
         self.overlap = overlap
@@ -169,12 +170,12 @@ class StepEngine():
         if self.overlap and last_of_group:
             self.ev_free[slot].record(main)
 
-    def _learn_start(self, buf, state, train):
+    def _learn_start(self, buf, state, train, t=0):
         """ELBO (+ gradient) of the step in draw buffer `buf`; starts the one collective of the path
         (flat-gradient SUM, RCCL over xGMI) and returns its handle."""
+        self.loss = self.loss_steps[t:t + 1]  # one slot per step: summed once at the end of run()
         ops.vae_elbo(state.params, self.Ybuf[buf], self.ezbuf[buf], (self.h0, self.h1, self.z),
                      self.obs_sigma, grads=self.grads if train else None, loss=self.loss, work=self.work)
-        self.loss_sum += self.loss
         return allreduce_sum_start(self.grads) if train else None
 
     def _learn_finish(self, handle, state, train):
@@ -190,6 +191,7 @@ class StepEngine():
         keys = [tuple(k) for k in keys]
         if not keys:
             return self.loss_sum
+        self.loss_steps = torch.zeros(len(keys), dtype=self.dtype, device=self.x.device)
         groups = [keys[i:i + self.G] for i in range(0, len(keys), self.G)]
         if self.overlap:
             for s in range(2):
@@ -208,10 +210,11 @@ class StepEngine():
                 self._produce(key, slot, i, i == len(grp) - 1, t & 1)
                 if pending is not None:
                     self._learn_finish(pending[0], state, train)
-                pending = (self._learn_start(t & 1, state, train),)
+                pending = (self._learn_start(t & 1, state, train, t),)
                 t += 1
         if pending is not None:
             self._learn_finish(pending[0], state, train)
+        torch.sum(self.loss_steps, dim=0, keepdim=True, out=self.loss_sum)
         return self.loss_sum
 
 
