@@ -2,7 +2,8 @@
 // into three bf16 planes each and six bf16 MFMA products per k16 step (tools/ub_bf16x3.hip has the
 // error analysis).  Measures what a first, un-pipelined kernel of that kind reaches at the C3 shape
 // (n = B = 4096) next to the library's f32-MFMA draw (0.55 ms); result quoted in DESIGN.md §7.
-//   build: hipcc -O3 --offload-arch=gfx950 tools/proto_draw_b3.hip -o tools/proto_draw_b3
+//   build: hipcc -O3 --offload-arch=gfx950 [-DPBK=64] tools/proto_draw_b3.hip -o tools/proto_draw_b3
+// (-DPBK=64: k-tile 64, 123 KB of LDS, one block per CU: 0.51 ms; default 0.50-0.53 ms)
 // Simple structure on purpose: 128 x 128 tile per 256-thread block (4 waves, 64 x 64 each), k-tile 32,
 // one LDS buffer, global loads one tile ahead in registers; occupancy (2 blocks per CU) hides the rest.
 #include <hip/hip_runtime.h>
@@ -15,7 +16,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TS = 128, BK = 32, ROWB = 80;  // tile edge, k-tile, LDS bytes per image row (64 + pad)
+#ifndef PBK
+#define PBK 32
+#endif
+constexpr int TS = 128, BK = PBK, ROWB = BK * 2 + 16;  // tile edge, k-tile, LDS bytes per image row (+ pad)
+constexpr int VPR = BK / 8;                            // 16-byte vectors per image row
+constexpr int NQ = 6 * TS * VPR / 256;                 // vectors per thread and k-tile
 
 // x -> three bf16 planes (plane stride `ps` elements); lower: zero strictly above the diagonal
 __global__ void split3(const float *x, __bf16 *out, int64_t rows, int64_t cols, int64_t ps, int lower) {
@@ -30,7 +36,7 @@ __global__ void split3(const float *x, __bf16 *out, int64_t rows, int64_t cols, 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void draw_b3(int n, int nb, const __bf16 *E3, const __bf16 *L3, float *Y) {
+__global__ __launch_bounds__(256, PBK == 32 ? 2 : 1) void draw_b3(int n, int nb, const __bf16 *E3, const __bf16 *L3, float *Y) {
   __shared__ __align__(16) unsigned char lds[6 * TS * ROWB];  // A planes 0..2, B planes 0..2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nrt = nb / TS, nct = n / TS;
@@ -41,13 +47,13 @@ __global__ __launch_bounds__(256, 2) void draw_b3(int n, int nb, const __bf16 *E
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int r = lane & 31, h = lane >> 5;
 
-  // loader: 6 images x 128 rows x 4 vectors (16 B) per k-tile = 3072 vectors, 12 per thread
-  i32x4 pre[12];
+  // loader: 6 images x 128 rows x BK/8 vectors (16 B) per k-tile, NQ per thread (12 at BK = 32)
+  i32x4 pre[NQ];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int v = tid + q * 256;
-      const int img = v / 512, row = (v % 512) >> 2, c = v & 3;
+      const int img = v / (TS * VPR), row = (v % (TS * VPR)) / VPR, c = v % VPR;
       const __bf16 *src = img < 3 ? E3 + img * psE + (m0 + row) * n + k0 + c * 8
                                   : L3 + (img - 3) * psL + (c0 + row) * n + k0 + c * 8;
       pre[q] = *reinterpret_cast<const i32x4 *>(src);
@@ -55,9 +61,9 @@ __global__ __launch_bounds__(256, 2) void draw_b3(int n, int nb, const __bf16 *E
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int v = tid + q * 256;
-      const int img = v / 512, row = (v % 512) >> 2, c = v & 3;
+      const int img = v / (TS * VPR), row = (v % (TS * VPR)) / VPR, c = v % VPR;
       *reinterpret_cast<i32x4 *>(lds + (img * TS + row) * ROWB + c * 16) = pre[q];
     }
   };
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void draw_b3(int n, int nb, const __bf16 *E
     __syncthreads();
     if (k0 + BK < kend) gload(k0 + BK);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       bf16x8 a[3][2], b[3][2];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
