@@ -1,0 +1,154 @@
+"""Seeded random-shape sweep of the entry points whose kernels switch paths with the shape (fast
+aligned tiles / generic ragged tiles / padded leading dimensions / batch maps), through the C ABI,
+against the CPU oracle or NumPy/LAPACK on identical inputs.  Complements the fixed cases of
+test_gpu_parity.py: sizes straddle the 32 / 64 / 128 / 256 tile and block edges, leading dimensions
+are padded (sub-views of wider buffers), batches straddle the 8-XCD map.
+
+Tolerances as in test_gpu_parity.py: float64 far below the 1e-5 of BASELINE.json, float32 1e-3 or
+better (the arithmetic here is well conditioned by construction, so tighter bounds are asserted).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [(np.float64, torch.float64), (np.float32, torch.float32)]
+EDGES = [1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 191, 255, 256, 257, 300, 383, 511, 512, 513, 640, 700]
+
+
+def rel(a, b):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def padded(a, tdt, pad):
+    """Device copy of the 2-D / 3-D array `a` living inside a buffer whose rows are `pad` elements
+    longer (leading dimension > row length), the surplus filled with NaN so that any read of it shows."""
+    a = np.asarray(a)
+    buf = torch.full(a.shape[:-1] + (a.shape[-1] + pad,), float("nan"), dtype=tdt, device=DEV)
+    view = buf[..., :a.shape[-1]]
+    view.copy_(torch.tensor(a, dtype=tdt, device=DEV))
+    return view
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gp_vae_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def spd(rng, batch, n):
+    """Well-conditioned SPD matrices (cond about 10) so that float32 forward errors stay at 1e-5."""
+    M = rng.standard_normal((batch, n, max(2 * n, 4)))
+    A = M @ M.transpose(0, 2, 1) / M.shape[2]
+    return A + 0.5 * np.eye(n)
+
+
+@pytest.mark.parametrize("ndt,tdt", DTYPES)
+def test_potrf_random_shapes_with_extra_rows(ops, ndt, tdt):
+    rng = np.random.default_rng(11)
+    tol = 1e-11 if ndt == np.float64 else 2e-5
+    for case in range(40):
+        n = int(rng.choice(EDGES))
+        batch = int(rng.choice([1, 2, 3, 7, 8, 9, 17]))
+        if batch * n * n > 6e6:
+            batch = max(1, int(6e6 // (n * n)))
+        m = int(rng.choice([0, 1, 2, 63, 64, 65, 130, 300]))
+        pad = int(rng.choice([0, 4, 12]))
+        A = spd(rng, batch, n)
+        X = rng.standard_normal((batch, m, n)) if m else None
+        Ad = padded(A.astype(ndt), tdt, pad)
+        Xd = padded(X.astype(ndt), tdt, pad) if m else None
+        info = ops.potrf_(Ad, Xd)
+        assert (info == 0).all(), (case, n, batch, m, pad)
+        L = np.linalg.cholesky(A)
+        assert rel(Ad, L) < tol, (case, n, batch, m, pad, rel(Ad, L))
+        if m:
+            want = np.stack([np.linalg.solve(L[b], X[b].T).T for b in range(batch)])  # X L^-T
+            assert rel(Xd, want) < 10 * tol, (case, n, batch, m, pad, rel(Xd, want))
+
+
+@pytest.mark.parametrize("ndt,tdt", DTYPES)
+def test_draw_and_trsm_random_shapes(ops, ndt, tdt):
+    rng = np.random.default_rng(12)
+    tol = 1e-12 if ndt == np.float64 else 1e-5
+    for case in range(40):
+        n, nb = int(rng.choice(EDGES)), int(rng.choice(EDGES))
+        pad = int(rng.choice([0, 4, 8]))
+        L = np.tril(rng.standard_normal((n, n))) + 4.0 * np.sqrt(n) * np.eye(n)
+        E, E2 = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
+        Fo, Yo = orc.gp_draw(L, E, 0.3, E2)
+        junk = np.triu(np.full((n, n), 9.0), 1)  # above the diagonal: must never be read as data
+        Ld = padded((L + junk).astype(ndt), tdt, pad)
+        Ed, E2d = padded(E.astype(ndt), tdt, pad), padded(E2.astype(ndt), tdt, pad)
+        F, Y = ops.draw(Ld, Ed, E2d, 0.3, want_f=True)
+        assert rel(F, Fo) < tol and rel(Y, Yo) < tol, (case, n, nb, pad, rel(F, Fo), rel(Y, Yo))
+        # the stand-alone solve against the same factor: X L^-T then X L^-1 = X (L L^T)^-1
+        Xd = padded(E.astype(ndt), tdt, pad)
+        ops.trsm_(Ld, Xd, trans=True)
+        w1 = np.linalg.solve(L, E.T).T
+        assert rel(Xd, w1) < 20 * tol, (case, n, nb, pad, "trans", rel(Xd, w1))
+        ops.trsm_(Ld, Xd, trans=False)
+        w2 = np.linalg.solve(L.T, w1.T).T
+        assert rel(Xd, w2) < 400 * tol, (case, n, nb, pad, "notrans", rel(Xd, w2))
+
+
+@pytest.mark.parametrize("ndt,tdt", DTYPES)
+def test_vae_elbo_random_shapes(ops, ndt, tdt):
+    rng = np.random.default_rng(13)
+    t = 1e-10 if ndt == np.float64 else 2e-4
+    for case in range(24):
+        B = int(rng.choice([1, 7, 16, 33, 128, 200, 256, 384]))
+        n = int(rng.choice([1, 19, 64, 100, 192, 300, 625, 1024]))
+        h0 = int(rng.choice([1, 3, 35, 50, 63, 64, 65, 200]))
+        h1 = int(rng.choice([1, 2, 30, 64, 129]))
+        z = int(rng.choice([1, 2, 10, 15, 40]))
+        p = {k: (6 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+        Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+        lo, go = orc.elbo_loss_and_grads(p, Y, ez, 0.1)
+        flat = torch.tensor(orc.flatten(p), dtype=tdt, device=DEV)
+        grads = torch.empty_like(flat)
+        Yd = torch.tensor(Y, dtype=tdt, device=DEV)
+        ezd = torch.tensor(ez, dtype=tdt, device=DEV)
+        loss = ops.vae_elbo(flat, Yd, ezd, (h0, h1, z), 0.1, grads=grads)
+        tag = (case, B, n, h0, h1, z)
+        assert abs(loss.item() - lo) < t * abs(lo), tag
+        gd = orc.unflatten(grads.cpu().numpy(), n, h0, h1, z)
+        for k in orc.PARAM_NAMES:
+            assert rel(gd[k], go[k]) < t, tag + (k, rel(gd[k], go[k]))
+        # evaluate-only call (no gradient buffers): same loss
+        l2 = ops.vae_elbo(flat, Yd, ezd, (h0, h1, z), 0.1)
+        assert abs(l2.item() - lo) < t * abs(lo), tag
+
+
+@pytest.mark.parametrize("ndt,tdt", DTYPES)
+def test_kriging_random_shapes(ops, ndt, tdt):
+    rng = np.random.default_rng(14)
+    for case in range(16):
+        n_obs = int(rng.choice([1, 5, 63, 64, 100, 257, 400]))
+        n_test = int(rng.choice([1, 17, 64, 130, 625]))
+        d = int(rng.choice([1, 2]))
+        x = rng.random((n_obs + n_test, d))
+        obs = np.sort(rng.permutation(n_obs + n_test)[:n_obs])
+        y = np.sin(4 * x[:, 0]) + 0.1 * rng.standard_normal(n_obs + n_test)
+        var, ls, sigma = 1.0 + rng.random(), 0.1 + 0.4 * rng.random(), 0.05 + 0.1 * rng.random()
+        xi = rng.standard_normal(n_test)
+        mo, so, vo = orc.gp_prediction(x, y, obs, var, ls, sigma, xi)
+        mask = np.ones(n_obs + n_test, bool)
+        mask[obs] = False
+        dv = lambda a: torch.tensor(np.asarray(a), dtype=tdt, device=DEV)
+        md, sd, vd, info = ops.krig_predict(dv(x[obs]), dv(x[mask]), dv(y[obs]), var, ls, sigma, 1e-5, xi=dv(xi))
+        tag = (case, n_obs, n_test, d)
+        assert info.item() == 0, tag
+        if ndt == np.float64:
+            assert rel(md, mo) < 1e-7 and np.abs(vd.cpu().numpy() - vo).max() < 1e-8 and rel(sd, so) < 1e-6, tag
+        else:  # f32: the observation noise sigma >= 0.05 bounds cond(k_xx + sigma I) by about n_obs * 40
+            assert rel(md, mo) < 3e-3, tag + (rel(md, mo),)
+            assert np.abs(vd.cpu().numpy() - vo).max() < 3e-3 * var, tag
