@@ -152,3 +152,70 @@ def test_kriging_random_shapes(ops, ndt, tdt):
         else:  # f32: the observation noise sigma >= 0.05 bounds cond(k_xx + sigma I) by about n_obs * 40
             assert rel(md, mo) < 3e-3, tag + (rel(md, mo),)
             assert np.abs(vd.cpu().numpy() - vo).max() < 3e-3 * var, tag
+
+
+@pytest.mark.parametrize("ndt,tdt", DTYPES)
+def test_decoder_random_shapes(ops, ndt, tdt):
+    rng = np.random.default_rng(15)
+    t = 1e-11 if ndt == np.float64 else 1e-4
+    for case in range(20):
+        C_ = int(rng.choice([1, 3, 16, 17, 100, 256, 300]))
+        n = int(rng.choice([1, 19, 64, 100, 300, 625, 1024]))
+        h0 = int(rng.choice([1, 3, 35, 50, 64, 65, 200, 600]))
+        h1 = int(rng.choice([1, 2, 30, 64, 129, 300]))
+        z = int(rng.choice([1, 2, 10, 15, 40]))
+        p = {k: (6 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+        Z, dF = rng.standard_normal((C_, z)), rng.standard_normal((C_, n))
+        dec = torch.tensor(np.concatenate([p[k].reshape(-1) for k in ("V1", "c1", "V2", "c2", "V3", "c3")]),
+                           dtype=tdt, device=DEV)
+        Zd, dFd = torch.tensor(Z, dtype=tdt, device=DEV), torch.tensor(dF, dtype=tdt, device=DEV)
+        tag = (case, C_, n, h0, h1, z)
+        assert rel(ops.decoder_fwd(dec, Zd, n, h0, h1), orc.decoder(p, Z)) < t, tag
+        assert rel(ops.decoder_vjp(dec, Zd, dFd, h0, h1), orc.decoder_vjp(p, Z, dF)) < t, tag
+
+
+def test_mvn_logp_random_shapes_f64(ops):
+    """float64 only: in float32 the gradient bounds depend on cond(K) (test_gpu_parity.py states them
+    per size); the path taken through the kernels is the same for both types."""
+    rng = np.random.default_rng(16)
+    for case in range(10):
+        n = int(rng.choice([1, 2, 31, 64, 65, 128, 150, 257, 400]))
+        d = int(rng.choice([1, 2]))
+        S = int(rng.choice([1, 2, 7, 9]))
+        x = rng.random((n, d))
+        var = rng.uniform(0.7, 1.4, S); ls = rng.uniform(0.1, 0.3, S)
+        jit = 1e-4
+        F = np.stack([np.linalg.cholesky(orc.exp_kernel2(x, x, var[s], ls[s], jit)) @ rng.standard_normal(n) for s in range(S)])
+        xd = torch.tensor(x if d == 2 else x[:, 0], dtype=torch.float64, device=DEV)
+        lp, gf, gv, gl, info = ops.mvn_logp(xd, torch.tensor(F, dtype=torch.float64, device=DEV), var, ls, jit)
+        assert (info == 0).all(), (case, n, d, S)
+        for s in range(S):
+            lo, gfo, gvo, glo = orc.mvn_logp_grads(x if d == 2 else x[:, 0], F[s], var[s], ls[s], jit)
+            tag = (case, n, d, S, s)
+            assert abs(lp[s].item() - lo) < 1e-8 * max(1.0, abs(lo)), tag
+            assert rel(gf[s], gfo) < 1e-6, tag + (rel(gf[s], gfo),)
+            assert abs(gv[s].item() - gvo) < 1e-6 * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < 1e-6 * max(1.0, abs(glo)), tag
+
+
+def test_kriging_batched_random_shapes_f64(ops):
+    rng = np.random.default_rng(17)
+    for case in range(8):
+        n_obs = int(rng.choice([1, 5, 63, 64, 100, 257]))
+        n_test = int(rng.choice([1, 17, 64, 130, 300]))
+        d = int(rng.choice([1, 2]))
+        S = int(rng.choice([1, 3, 8, 11]))
+        x = rng.random((n_obs + n_test, d))
+        obs = np.sort(rng.permutation(n_obs + n_test)[:n_obs])
+        mask = np.ones(n_obs + n_test, bool)
+        mask[obs] = False
+        y = np.sin(4 * x[:, 0]) + 0.1 * rng.standard_normal(n_obs + n_test)
+        var = rng.uniform(0.5, 1.5, S); ls = rng.uniform(0.1, 0.4, S); sig = rng.uniform(0.05, 0.15, S)
+        xi = rng.standard_normal((S, n_test))
+        dv = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=DEV)
+        m, p, v, info = ops.krig_predict_batched(dv(x[obs]), dv(x[mask]), dv(y[obs]), var, ls, sig, 1e-5, dv(xi))
+        assert (info == 0).all(), (case, n_obs, n_test, d, S)
+        for s in range(S):
+            mo, po, vo = orc.gp_prediction(x, y, obs, var[s], ls[s], sig[s], xi[s])
+            tag = (case, n_obs, n_test, d, S, s)
+            assert rel(m[s], mo) < 1e-7 and rel(p[s], po) < 1e-6, tag
+            assert np.abs(v[s].cpu().numpy() - vo).max() < 1e-8, tag
