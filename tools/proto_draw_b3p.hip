@@ -2,12 +2,26 @@
 // the in-wave software pipeline of gemm_core.hpp's PipeKC and one wave per SIMD:
 //   * 256 x 128 tile per 256-thread block (4 waves as 2 x 2, each 128 x 64: 18 fragment reads per 48
 //     MFMAs instead of 12 per 24), one block per CU, 512 registers per lane;
-//   * LDS double buffer of k-tiles of 32; image [plane][8-k chunk][row][16 B] (+64 B per chunk
-//     plane): fragment reads and tile writes are conflict-free without row padding;
-//   * per k-tile: first half = MFMAs of k16 step 0 with the ds_writes of tile t+1 and the reads of
-//     step 1's fragments between them, barrier, second half = MFMAs of step 1 with the global loads
-//     of tile t+2 and the reads of tile t+1's step-0 fragments between them
-//     (__builtin_amdgcn_sched_group_barrier fixes the interleave).
+//   * LDS double buffer of k-tiles of 32; image [plane][8-k chunk][row][16 B] (+32 B per chunk
+//     plane): fragment reads (4 x 16 lanes, 64 banks) and tile writes (8 x 8 lanes over a 128-byte
+//     window) are both conflict-free without row padding (SQ_LDS_BANK_CONFLICT 0; +64 B: 12 %);
+//   * per k-tile: first half = MFMAs of k16 step 0 with the reads of step 1's fragments, then the
+//     ds_writes of tile t+1 each followed by the global load of the same register for tile t+2
+//     (a whole tile of latency cover), barrier, second half = MFMAs of step 1 with the reads of
+//     tile t+1's step-0 fragments (__builtin_amdgcn_sched_group_barrier fixes the interleave).
+// Measured (MI355X, n = nb = 4096, error 9e-8 of sum|e l|):
+//   this file                                        0.395-0.41 ms  (library f32 draw 0.55; un-pipelined
+//                                                                    prototype 0.50)
+//   -DSCHED=1 (writes early, loads late: 78 instead of 96 MFMAs of load lead)   0.44 ms
+//   -DEXP_NOLOAD  (no global loads in the loop; results wrong)                  0.34 ms
+//   -DEXP_NOSTAGE (no loads, no LDS writes, half the fragment reads)            0.29 ms
+//   MFMA pipe alone: 405 k cycles = 0.24 ms at the 1.7 GHz the chip holds under this load
+// PMC: 606 k cycles per launch, MFMA pipe 67 % busy, no bank conflicts.  So of the 0.16 ms above the
+// MFMA time, ~0.05 is barriers / prologue / epilogue, ~0.05 the LDS writes (ds_write_b128 holds the
+// wave's issue for 13-26 cycles: the 128 x 64 wave tile needs 18 of them per 96 MFMAs) and ~0.06
+// the global loads (their latency under load exceeds 78 MFMA times).  Levers for the library
+// version: 256 x 256 block tiles (0.75x the staged bytes per MFMA), the B operand straight from
+// global memory into fragment registers, a deeper load lead.
 //   build: hipcc -O3 --offload-arch=gfx950 tools/proto_draw_b3p.hip -o tools/proto_draw_b3p
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -21,11 +35,20 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ i32x4 raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
+#ifndef PAD
+#define PAD 32  // ds_write_b128 banks in groups of 8 lanes over a 128-byte window: chunk planes 32 B apart
+#endif
 constexpr int TM = 256, TN = 128, NT = 256, BK = 32, WFM = 4, WFN = 2;
-constexpr int CPA = TM * 16 + 64, CPB = TN * 16 + 64;  // bytes per (plane, chunk) of the A / B image
+constexpr int CPA = TM * 16 + PAD, CPB = TN * 16 + PAD;  // bytes per (plane, chunk) of the A / B image
 constexpr int A_BYTES = 12 * CPA, STAGE = 12 * (CPA + CPB);
 constexpr int NQA = 12, NQB = 6;                       // 16-byte vectors per thread and k-tile
 
+#ifndef SCHED
+#define SCHED 0
+#endif
+#ifndef LEAD
+#define LEAD 6
+#endif
 #ifndef NOSGB
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #else
@@ -112,36 +135,61 @@ struct Pipe {
   }
 
   // k-tile in buffer CUR.  HAS1 / HAS2: tiles t+1 / t+2 exist.
-  template <int CUR, bool HAS1, bool HAS2>
+  template <int CUR, bool HAS1_, bool HAS2_>
   __device__ __forceinline__ void tile(unsigned char *lds, int k0) {
     constexpr int NXT = CUR ^ 1;
-    // ---- first half: MFMAs of step 0 | writes of tile t+1, reads of step 1's fragments
+#if defined(EXP_NOLOAD)   // timing experiments only (results wrong): no global loads in the loop
+    constexpr bool HAS1 = HAS1_, HAS2 = false;
+#elif defined(EXP_NOSTAGE)  // ... and no LDS writes either
+    constexpr bool HAS1 = false, HAS2 = false;
+#else
+    constexpr bool HAS1 = HAS1_, HAS2 = HAS2_;
+#endif
+    // ---- first half: MFMAs of step 0 | reads of step 1's fragments, then tile t+1 written to the
+    // other buffer and, register by register, tile t+2 requested (a whole tile of latency cover)
     __builtin_amdgcn_sched_barrier(0);
     read_sub<CUR, 1>(lds);
     if (HAS1) lstore<NXT>(lds);
+    if (HAS2) gload(k0 + 2 * BK);
     mma_sub<0>();
+#if SCHED == 1  // one memory instruction per MFMA gap: 9 x 2 reads, 18 writes, 18 loads
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x100, 1); }   // MFMA, DS read
+    for (int i = 0; i < 9; ++i) { SGB(0x008, 1); SGB(0x100, 2); }
     if (HAS1) {
 #pragma unroll
-      for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x200, 1); }  // MFMA, DS write
-      SGB(0x008, 12);
-    } else {
-      SGB(0x008, 30);
+      for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x200, 1); }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    // ---- second half: MFMAs of step 1 | loads of tile t+2, reads of tile t+1's step-0 fragments
-    if (HAS2) gload(k0 + 2 * BK);
-    if (HAS1) read_sub<NXT, 0>(lds);
-    mma_sub<1>();
     if (HAS2) {
 #pragma unroll
-      for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x020, 1); }  // MFMA, VMEM read
+      for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x020, 1); }
     }
+#else
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x100, 1); }   // MFMA, DS read
+    SGB(0x008, LEAD);
     if (HAS1) {
 #pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        SGB(0x008, 1);
+        SGB(0x200, 1);            // DS write
+        if (HAS2) SGB(0x020, 1);  // VMEM read
+      }
+    }
+#endif
+    SGB(0x008, 48);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- second half: MFMAs of step 1 | reads of tile t+1's step-0 fragments
+    if (HAS1) read_sub<NXT, 0>(lds);
+    mma_sub<1>();
+    if (HAS1) {
+#if SCHED == 1
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { SGB(0x008, 1); SGB(0x100, 2); }
+#else
+#pragma unroll
       for (int i = 0; i < 18; ++i) { SGB(0x008, 1); SGB(0x100, 1); }
+#endif
     }
     SGB(0x008, 48);
     __builtin_amdgcn_sched_barrier(0);
