@@ -95,9 +95,10 @@ def pmc_traffic():
         return None, None
 
 
-def potrf_microbench(ops, x, batch=32, iters=3, dtype=torch.float32):
+def potrf_microbench(ops, x, batch=32, iters=5, dtype=torch.float32, parts=1):
     """Batched Cholesky TFLOP/s: `batch` Gram matrices with ls on the ladder linspace(0.05, 1, batch),
-    var = 1 (batch 32)."""
+    var = 1 (batch 32).  parts > 1: the batch is issued as that many sub-batches
+    on side streams (ops.potrf_overlapped_), timed fork to join on the current stream."""
     dev = x.device
     x = x.to(dtype)
     ls = torch.linspace(0.05, 1.0, batch, device=dev, dtype=dtype)
@@ -109,13 +110,16 @@ def potrf_microbench(ops, x, batch=32, iters=3, dtype=torch.float32):
         ops.gram_se(x, x, var, ls, JITTER, out=Kb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        info = ops.potrf_(Kb, zero_upper=False, nan_on_fail=False)
+        if parts > 1:
+            info = ops.potrf_overlapped_(Kb, parts=parts, zero_upper=False, nan_on_fail=False)
+        else:
+            info = ops.potrf_(Kb, zero_upper=False, nan_on_fail=False)
         e1.record()
         torch.cuda.synchronize()
         if it > 0:
             times.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(times))
-    return {"batch": batch, "n": N, "dtype": "f32" if dtype == torch.float32 else "f64", "ms": t * 1e3,
+    return {"batch": batch, "n": N, "streams": parts, "dtype": "f32" if dtype == torch.float32 else "f64", "ms": t * 1e3,
             "tflops": batch * N ** 3 / 3 / t / 1e12, "all_pd": bool((info == 0).all().item())}
 
 
@@ -168,8 +172,9 @@ def main():
     loss_last = float(eng.loss.item())
 
     # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
-    chol = [potrf_microbench(ops, x, batch=32), potrf_microbench(ops, x, batch=args.group),
-            potrf_microbench(ops, x, batch=16, dtype=torch.float64)]
+    chol = [potrf_microbench(ops, x, batch=32, parts=2), potrf_microbench(ops, x, batch=args.group),
+            potrf_microbench(ops, x, batch=16, dtype=torch.float64), potrf_microbench(ops, x, batch=32),
+            potrf_microbench(ops, x, batch=64, parts=2)]
     if world > 1:
         for c in chol:
             tt = torch.tensor([c["tflops"], float(c["all_pd"])], dtype=torch.float64, device=dev)
@@ -211,6 +216,8 @@ def main():
             "cholesky": chol[0],
             "cholesky_factor_group": chol[1],
             "cholesky_f64": chol[2],
+            "cholesky_single_stream": chol[3],
+            "cholesky_batch64": chol[4],
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:

@@ -125,6 +125,42 @@ def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None):
     return info
 
 
+_side_streams = {}
+
+
+def potrf_overlapped_(A, parts=2, zero_upper=True, nan_on_fail=True):
+    """potrf_ of a batch [batch,n,n] issued as `parts` sub-batches on side streams (forked from and
+    joined back to the current stream): the latency-bound panel launches of one sub-batch run under
+    the MFMA-bound trailing updates of the other.  Same results as potrf_ (the matrices are
+    independent); pays from batch 32 up at n = 4096 (+3-5 %), loses below.  Returns info [batch]."""
+    _dev(A)
+    if A.dim() != 3:
+        raise GpvaeError("potrf_overlapped_: A must be [batch,n,n]")
+    batch = A.shape[0]
+    parts = max(1, min(int(parts), batch))
+    if parts == 1:
+        return potrf_(A, zero_upper=zero_upper, nan_on_fail=nan_on_fail)
+    key = (A.device.index, parts)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=A.device) for _ in range(parts)]
+    cur = torch.cuda.current_stream(A.device)
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    bounds = [batch * i // parts for i in range(parts + 1)]
+    infos = []
+    for i, s in enumerate(_side_streams[key]):
+        s.wait_event(fork)
+        with torch.cuda.stream(s):
+            sub = A[bounds[i]:bounds[i + 1]]
+            sub.record_stream(s)
+            infos.append(potrf_(sub, zero_upper=zero_upper, nan_on_fail=nan_on_fail))
+            infos[-1].record_stream(cur)
+        join = torch.cuda.Event()
+        join.record(s)
+        cur.wait_event(join)
+    return torch.cat(infos)
+
+
 def trsm_(L, X, trans=True):
     """In place X <- X L^-T (trans, every row x becomes the y with L y = x) or X <- X L^-1 (every row
     becomes the y with L^T y = x) against an existing lower factor L [n,n]; X [m,n].  Both in turn give

@@ -195,6 +195,22 @@ def test_potrf_tile_map_batches(ops, batch):
         assert rel(A[b], L) < 1e-12 and rel(Xd[b], orc.right_solve_lt(L, X[b])) < 1e-11
 
 
+def test_potrf_overlapped_sub_batches(ops):
+    """The sub-batch / side-stream form gives the factors and info values of the plain call."""
+    rng = np.random.default_rng(31)
+    n, batch = 200, 7
+    M = rng.standard_normal((batch, n, 2 * n))
+    A = M @ M.transpose(0, 2, 1) / (2 * n) + 0.1 * np.eye(n)
+    A[5] = -A[5]  # not positive definite: info > 0 must come back in position 5
+    for parts in (1, 2, 3, 9):
+        ref, got = dev(A, torch.float32), dev(A, torch.float32)
+        i0 = ops.potrf_(ref)
+        i1 = ops.potrf_overlapped_(got, parts=parts)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and i1[5].item() > 0 and (i1[:5] == 0).all()
+        assert torch.equal(torch.nan_to_num(ref), torch.nan_to_num(got))
+
+
 def test_potrf_near_rank_one(ops):
     """Long lengthscales (the heavy tail of the training prior InverseGamma(1, .1), vae.py:157) make
     K ~ var 11^T + jitter I.  fp32 LAPACK factors these; so must the HIP path, with a backward error
