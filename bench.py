@@ -173,7 +173,7 @@ def main():
 
     # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
     chol = [potrf_microbench(ops, x, batch=32, parts=2), potrf_microbench(ops, x, batch=args.group),
-            potrf_microbench(ops, x, batch=16, dtype=torch.float64), potrf_microbench(ops, x, batch=32),
+            potrf_microbench(ops, x, batch=16, dtype=torch.float64, parts=2), potrf_microbench(ops, x, batch=32),
             potrf_microbench(ops, x, batch=64, parts=2)]
     if world > 1:
         for c in chol:
