@@ -172,9 +172,10 @@ def main():
     loss_last = float(eng.loss.item())
 
     # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
-    chol = [potrf_microbench(ops, x, batch=32, parts=2), potrf_microbench(ops, x, batch=args.group),
-            potrf_microbench(ops, x, batch=16, dtype=torch.float64, parts=2), potrf_microbench(ops, x, batch=32),
-            potrf_microbench(ops, x, batch=64, parts=2)]
+    chol = [potrf_microbench(ops, x, batch=32), potrf_microbench(ops, x, batch=args.group),
+            potrf_microbench(ops, x, batch=16, dtype=torch.float64),
+            potrf_microbench(ops, x, batch=32, parts=2), potrf_microbench(ops, x, batch=64, parts=2),
+            potrf_microbench(ops, x, batch=16, dtype=torch.float64, parts=2)]
     if world > 1:
         for c in chol:
             tt = torch.tensor([c["tflops"], float(c["all_pd"])], dtype=torch.float64, device=dev)
@@ -216,8 +217,9 @@ def main():
             "cholesky": chol[0],
             "cholesky_factor_group": chol[1],
             "cholesky_f64": chol[2],
-            "cholesky_single_stream": chol[3],
-            "cholesky_batch64": chol[4],
+            "cholesky_two_streams": chol[3],
+            "cholesky_batch64_two_streams": chol[4],
+            "cholesky_f64_two_streams": chol[5],
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
         if world == 1 and not args.no_cpu_baseline:
