@@ -140,7 +140,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from gp_vae_amd import ops
     from gp_vae_amd.vae import StepEngine, SVIState, init_params
 
