@@ -19,6 +19,14 @@ import os
 import sys
 import time
 
+# One hardware queue per stream in use (main, factor stream, RCCL's stream, two side streams of the
+# Cholesky micro-benchmark): with HIP's default of 4 the collective's stream shares a queue with the
+# factor stream, its packets wait behind a whole factor group and the overlap is lost.
+# Read by the HIP runtime when it initialises, so it must be set before the first HIP call.
+# (The GPU boxes export 4, HIP's default, so raise rather than setdefault.)
+if int(os.environ.get("GPU_MAX_HW_QUEUES") or 4) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -131,6 +139,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="single GPU: create a one-rank RCCL group and run the per-step all-reduce anyway")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,9 +149,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    from gp_vae_amd import ops
+    from gp_vae_amd import ops, parallel
+    parallel.FORCE_COLLECTIVE = bool(args.force_collective)
     from gp_vae_amd.vae import StepEngine, SVIState, init_params
 
     dev = torch.device("cuda", local)
@@ -161,6 +174,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     eng.run([(1, i) for i in range(args.steps)], state, train=True)
+    host_enqueue = time.perf_counter() - t0  # the host's share: all launches of the timed steps issued
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -208,12 +222,14 @@ def main():
                                    "full step gram+potrf+draw+ELBO fwd/bwd+Adam",
                        "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
                        "z_dim": DIMS[2], "parallelism": "dp%d" % world,
-                       "factor_stream_overlap": not args.no_overlap, "factor_group": args.group},
+                       "factor_stream_overlap": not args.no_overlap, "factor_group": args.group,
+                       "forced_single_rank_collective": bool(args.force_collective)},
             "roofline": {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
                          "traffic": None, "avg_launch_ms": draw_ms, "flop_per_launch": flop},
             "final_loss": loss_last,
+            "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "cholesky": chol[0],
             "cholesky_factor_group": chol[1],
             "cholesky_f64": chol[2],
@@ -225,7 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
 

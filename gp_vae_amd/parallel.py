@@ -9,6 +9,15 @@ import numpy as np
 import torch.distributed as dist
 
 
+# dev switch (bench.py --force-collective): run the collective on a single-rank group too, so that its
+# stream choreography and cost can be exercised on one GPU
+FORCE_COLLECTIVE = False
+
+
+def _collective_on():
+    return dist_info()[1] > 1 or (FORCE_COLLECTIVE and dist.is_available() and dist.is_initialized())
+
+
 def dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -17,7 +26,7 @@ def dist_info():
 
 def allreduce_sum_(t):
     """In-place SUM over ranks of one flat tensor (no-op on a single rank)."""
-    if dist_info()[1] > 1:
+    if _collective_on():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -26,7 +35,7 @@ def allreduce_sum_start(t):
     """Start the in-place SUM over ranks; returns a handle for allreduce_wait (None on one rank).
     The collective runs on RCCL's own stream once the current stream's work on `t` is done, so
     kernels enqueued after this call overlap with it."""
-    if dist_info()[1] > 1:
+    if _collective_on():
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
     return None
 

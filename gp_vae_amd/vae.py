@@ -18,6 +18,7 @@ MI355X-first structure of the step loop (`StepEngine`):
     concatenated batch.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -89,6 +90,13 @@ class StepEngine():
         self.obs_sigma = obs_sigma
         self.hyper_sampler = hyper_sampler
         self.rank, self.world = dist_info()
+        if (dist.is_available() and dist.is_initialized() and overlap
+                and int(os.environ.get("GPU_MAX_HW_QUEUES") or 4) < 8):
+            # the collective's stream would share a hardware queue with the factor stream and wait
+            # behind whole factor groups (gp_vae_amd/__init__.py)
+            import warnings
+            warnings.warn("gp_vae_amd: GPU_MAX_HW_QUEUES < 8 with torch.distributed active — set it to 8 "
+                          "before the first HIP call, or the factor stream no longer overlaps the training steps")
         dev = self.x.device
         n, B = self.n, self.B
         self.G = max(1, int(group))
