@@ -13,6 +13,7 @@
 //   this file                                        0.395-0.41 ms  (library f32 draw 0.55; un-pipelined
 //                                                                    prototype 0.50)
 //   -DSCHED=1 (writes early, loads late: 78 instead of 96 MFMAs of load lead)   0.44 ms
+//   -DNOSGB   (no sched_group_barrier: the compiler's own interleave)           0.47 ms
 //   -DEXP_NOLOAD  (no global loads in the loop; results wrong)                  0.34 ms
 //   -DEXP_NOSTAGE (no loads, no LDS writes, half the fragment reads)            0.29 ms
 //   MFMA pipe alone: 405 k cycles = 0.24 ms at the 1.7 GHz the chip holds under this load
