@@ -130,3 +130,40 @@ def test_step_engine_two_ranks_pipelined_allreduce(tmp_path):
     assert rel(r0["params"], st.params.cpu().numpy()) < 1e-9
     assert abs(float(r0["loss"][0]) - losses[0]) < 1e-9 * abs(losses[0])
     assert abs(float(r1["loss"][0]) - losses[1]) < 1e-9 * abs(losses[1])
+
+
+def _engine_rccl_worker(rank, port, tmp):
+    """The engine's pipelined loop with the REAL RCCL calls (async all-reduce, stream wait) on a
+    one-rank group: same code path as N > 1 apart from the wire."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from gp_vae_amd import parallel
+        from gp_vae_amd.vae import StepEngine, SVIState, init_params
+        parallel.FORCE_COLLECTIVE = True
+        n, B, dims = 96, 40, (12, 9, 4)
+        x = np.arange(0, 1, 1 / n)
+        eng = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float64, seed=3, group=2)
+        st = SVIState(init_params(n, *dims, 7, torch.float64, DEV) * 5)
+        loss = eng.run([(2, i) for i in range(6)], st, train=True)
+        np.savez(os.path.join(tmp, "rccl.npz"), params=st.params.cpu().numpy(), loss=loss.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_engine_with_rccl_collective_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+    from gp_vae_amd.vae import StepEngine, SVIState, init_params
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_engine_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "rccl.npz")
+    n, B, dims = 96, 40, (12, 9, 4)
+    x = np.arange(0, 1, 1 / n)
+    eng = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float64, seed=3, group=2)
+    st = SVIState(init_params(n, *dims, 7, torch.float64, DEV) * 5)
+    loss = eng.run([(2, i) for i in range(6)], st, train=True)
+    assert rel(got["params"], st.params.cpu().numpy()) < 1e-10
+    assert abs(float(got["loss"][0]) - loss.item()) < 1e-10 * abs(loss.item())
