@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_F64_MFMA_TFLOPS = 78.6   # dense f64 matrix peak
+PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md
 GRID = 64
 N = GRID * GRID
 B = 4096
@@ -131,6 +132,147 @@ def potrf_microbench(ops, x, batch=32, iters=5, dtype=torch.float32, parts=1):
             "tflops": batch * N ** 3 / 3 / t / 1e12, "all_pd": bool((info == 0).all().item())}
 
 
+def _event_time(f, reps):
+    """Mean seconds per call of f() between HIP events on the current stream (one untimed call first)."""
+    f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def extras(ops, x, dev):
+    """Bounded side measurements under the driver's clock (about 5 s in all, rank 0, N = 1):
+    the Gram builder's achieved HBM write rate (its bound), and one number each for
+    the other BASELINE.json configurations C2, C4 and C5.  Their parity is the tests' business."""
+    import math
+    from gp_vae_amd.vae import StepEngine, SVIState, init_params, decoder_list_from_flat
+    from gp_vae_amd.inference import VAEInference
+    out = {}
+    # a1: Gram build at the training factor group's shape (16 x 4096 x 4096), f32 and f64
+    for dt, tag in ((torch.float32, "gram"), (torch.float64, "gram_f64")):
+        xx = x.to(dt)
+        ls = torch.linspace(0.05, 1.0, 16, device=dev, dtype=dt)
+        var = torch.ones(16, device=dev, dtype=dt)
+        Kb = torch.empty((16, N, N), device=dev, dtype=dt)
+        t = _event_time(lambda: ops.gram_se(xx, xx, var, ls, JITTER, out=Kb), 10)
+        nbytes = 16 * N * N * Kb.element_size()
+        out[tag] = {"kernel": "gram_se_kernel", "batch": 16, "n": N, "bytes": nbytes, "ms": t * 1e3,
+                    "GB_per_s": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / PEAK_HBM_GBS,
+                    "bound": "hbm write"}
+        del Kb
+    # C2: 1D n = 1024, B = 4096, reference MLP 35/30/10, whole training step
+    x1 = torch.arange(1024, dtype=torch.float32, device=dev) / 1024
+    eng = StepEngine(x1, 1e-4, (35, 30, 10), 4096, LR, dtype=torch.float32, seed=1, group=16)
+    st = SVIState(init_params(1024, 35, 30, 10, 1, torch.float32, dev))
+    eng.run([(0, i) for i in range(32)], st, train=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run([(1, i) for i in range(256)], st, train=True)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 256
+    out["c2"] = {"workload": "C2: 1D n=1024, B=4096, VAE 1024-35-30-10, f32, full training step",
+                 "ms_per_step": t * 1e3, "draws_per_s": 4096 / t}
+    del eng, st
+    # C4: the n_obs = 32768 f64 factorisation (8 GiB in place), SE Gram of a 2D point set + nugget
+    n4 = 32768
+    g = torch.arange(192, dtype=torch.float64, device=dev) / 192
+    u, v = torch.meshgrid(g, g, indexing="xy")
+    pts = torch.stack([u.reshape(-1), v.reshape(-1)], 1)
+    idx = torch.tensor(np.sort(np.random.default_rng(0).permutation(192 * 192)[:n4]), device=dev)
+    A = ops.gram_se(pts[idx].contiguous(), pts[idx].contiguous(), 1.0, 0.2, 1e-5)
+    A.diagonal().add_(0.05)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    info = ops.potrf_(A, zero_upper=False, nan_on_fail=False)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3
+    out["c4_potrf_f64"] = {"workload": "C4: Cholesky of the 32768 x 32768 f64 kriging matrix (192x192 grid subset)",
+                           "n": n4, "s": t, "tflops": n4 ** 3 / 3 / t / 1e12,
+                           "frac_of_mfma_peak": n4 ** 3 / 3 / t / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                           "pd": bool((info == 0).all().item())}
+    del A
+    # C5: VAE-prior regression potential + gradient, 1024 chains, decoder 10-30-35-300
+    n5, dims5 = 300, (35, 30, 10)
+    dec = decoder_list_from_flat(init_params(n5, *dims5, 1, torch.float32, dev), n5, *dims5)
+    x5 = np.arange(0, 1, 1 / n5)
+    inf = VAEInference(None, dec, dims5[2], 1, x5, np.sin(6 * x5), [20, 23, 100, 110, 117, 130, 133, 140, 170, 190],
+                       {}, dtype=torch.float32)
+    z = ops.randn((1024, dims5[2]), torch.float32, dev, seed=5)
+    lsig = torch.full((1024,), math.log(0.1), device=dev)
+    t = _event_time(lambda: inf.potential_and_grad(z, lsig), 200)
+    out["c5"] = {"workload": "C5: VAEInference.regression potential + gradient, 1024 chains, decoder 10-30-35-300, f32",
+                 "grad_evals_per_s": 1024 / t, "ms_per_batched_eval": t * 1e3}
+    return out
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, BEFORE this process has made any HIP call (a process
+    that touched the GPU is never re-executed).  Rank 0's stdout carries the JSON line; the exit code
+    is non-zero if any rank failed."""
+    import subprocess
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                "MASTER_PORT": os.environ.get("MASTER_PORT") or str(free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + 30.0  # a rank died: the others would hang in a collective
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    bad = [(r, rc) for r, rc in enumerate(p.returncode for p in procs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        raise SystemExit(1)
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launcher, the rendezvous and the one collective of the path on gloo/CPU with a
+    stand-in gradient; no HIP call, no throughput.  Exists so that `--gpus N` is testable without GPUs."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gp_vae_amd import parallel
+    g = torch.full((1024,), float(rank + 1))
+    h = parallel.allreduce_sum_start(g)
+    parallel.allreduce_wait(h)
+    want = world * (world + 1) / 2
+    assert float(g[0]) == want and float(g[-1]) == want, (float(g[0]), want)
+    seen = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "GP-prior VAE training draws/sec at 64x64 grid", "value": None,
+                          "unit": "draws/s", "n_gpus": world, "rccl_world": seen, "dry_run": True,
+                          "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "allreduce_sum_checked": want}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,11 +283,24 @@ def main():
     ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
     ap.add_argument("--force-collective", action="store_true",
                     help="single GPU: create a one-rank RCCL group and run the per-step all-reduce anyway")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher + rendezvous + all-reduce on gloo/CPU only (no GPU work, no number)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the bounded side measurements (Gram HBM rate, C2, C4 potrf, C5)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])  # parent: no HIP call has been made
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d — refusing to label a "
+                         "%d-rank run as %d GPUs" % (args.gpus, world, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -177,10 +332,13 @@ def main():
     host_enqueue = time.perf_counter() - t0  # the host's share: all launches of the timed steps issued
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3] * 2  # per-rank ms/step: min, max over ranks
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        rank_ms = [-float(tt[1].item()) / args.steps * 1e3, float(tt[0].item()) / args.steps * 1e3]
+        elapsed = float(tt[0].item())
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
     draw_ms = float(np.mean([a.elapsed_time(b) for a, b in eng.draw_events])) if eng.draw_events else None
     eng.draw_events = None
     loss_last = float(eng.loss.item())
@@ -213,6 +371,8 @@ def main():
             "value": B * args.steps * world / elapsed,
             "unit": "draws/s",
             "n_gpus": world,
+            "rccl_world": rccl_world,
+            "ms_per_step_rank_min_max": rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -242,6 +402,8 @@ def main():
             out.update({"cholesky_two_streams": chol[3], "cholesky_batch64_two_streams": chol[4],
                         "cholesky_f64_two_streams": chol[5]})
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
+        if world == 1 and not args.no_extras:
+            out.update(extras(ops, x, dev))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

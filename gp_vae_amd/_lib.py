@@ -31,6 +31,8 @@ SIGNATURES = {
     "gpvae_trsm": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64]),
     "gpvae_draw": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64,
                         _vp, _i64]),
+    "gpvae_draw_batched": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                _i64, _vp, _i64]),
     "gpvae_randn": (_i, [_vp, _i, _i64, _u64, _u64, _vp]),
     "gpvae_krig_workspace_bytes": (_i64, [_i, _i64, _i64]),
     "gpvae_krig_predict": (_i, [_vp, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp,
@@ -45,6 +47,8 @@ SIGNATURES = {
     "gpvae_vae_workspace_bytes": (_i64, [_i, _i64, _i64, _i, _i, _i]),
     "gpvae_vae_elbo": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _d, _vp, _vp,
                             _vp]),
+    "gpvae_encoder_workspace_bytes": (_i64, [_i, _i64, _i64, _i, _i, _i]),
+    "gpvae_encoder_fwd": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gpvae_adam": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d]),
     "gpvae_decoder_workspace_bytes": (_i64, [_i, _i64, _i64, _i, _i, _i]),
     "gpvae_decoder_fwd": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),

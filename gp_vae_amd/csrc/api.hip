@@ -14,7 +14,9 @@ void set_error(const char *fmt, ...) {
 extern "C" int gpvae_abi_version(void) { return GPVAE_ABI_VERSION; }
 extern "C" const char *gpvae_last_error(void) { return gpvae::g_err; }
 
-// ---- developer probe (not part of include/gpvae.h): shader clock under the caller's load ------------
+#ifdef GPVAE_DEV
+// ---- developer probe (make DEV=1 only; not exported by the product build, not in include/gpvae.h):
+// shader clock under the caller's load
 // One wave spins on dependent FMAs for `iters` iterations and reports
 // (delta s_memtime [shader cycles], delta s_memrealtime [100 MHz ticks]) into out[0..1].
 __global__ void gpvae_dev_clock_kernel(int iters, unsigned long long *out) {
@@ -35,3 +37,4 @@ extern "C" int gpvae_dev_clock(void *stream, int iters, void *out3_u64) {
                      (unsigned long long *)out3_u64);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#endif  // GPVAE_DEV

@@ -106,6 +106,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void draw_kernel(
   }
 }
 
+
+// ---- one draw per factor: the Predictive(gp.sample) call with hyper-parameters left None ------------
+// (vae.py:226, toy_examples.py:88, gp.py:171-176: every sample has its own K, L, sigma.)
+// f_b = L_b e_b is a triangular matrix-vector product per sample: n^2/2 * s bytes of L read once
+// => HBM-bound.  One workgroup per (64-row block, sample): e_b staged in LDS, one wave per row at a
+// time, lanes along the row (coalesced 256-byte reads of L), wave reduction.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void draw_batched_kernel(
+    int64_t n, const T *L, int64_t ldl, int64_t strideL, const T *E, int64_t lde, const T *E2,
+    int64_t lde2, const T *sigma, T *F, int64_t ldf, T *Y, int64_t ldy) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *e = reinterpret_cast<T *>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  const int64_t iend = (i0 + 64 < n) ? i0 + 64 : n;
+  const T *Lb = L + b * strideL;
+  const T *Eb = E + b * lde;
+  for (int64_t j = tid; j < iend; j += NTHREADS) e[j] = Eb[j];
+  __syncthreads();
+  const T sg = (E2 != nullptr) ? sigma[b] : T(0);
+  for (int64_t i = i0 + wave; i < iend; i += NTHREADS / 64) {
+    const T *row = Lb + i * ldl;
+    T a[4] = {T(0), T(0), T(0), T(0)};
+    int u = 0;
+    for (int64_t j = lane; j <= i; j += 64, u = (u + 1) & 3) a[u] += row[j] * e[j];
+    const T f = wave_sum<T>((a[0] + a[1]) + (a[2] + a[3]));
+    if (lane == 0) {
+      if (F != nullptr) F[b * ldf + i] = f;
+      if (Y != nullptr) Y[b * ldy + i] = (E2 != nullptr) ? f + sg * E2[b * lde2 + i] : f;
+    }
+  }
+}
+
 // ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------
 // counter = (i_lo, i_hi, stream_lo, stream_hi) with i = element index / 4, key = (seed_lo, seed_hi);
 // the 4 output words give 4 normals: (u0,u1) -> (r cos, r sin), (u2,u3) -> (r cos, r sin),
@@ -208,6 +242,42 @@ extern "C" int gpvae_draw(void *stream, int dtype, int64_t n, int64_t nb, const 
     else launch(double{}, std::false_type{});
   }
   GPVAE_CHECK_LAUNCH("gpvae_draw");
+  return 0;
+}
+
+extern "C" int gpvae_draw_batched(void *stream, int dtype, int64_t n, int64_t nb, const void *L,
+                                  int64_t ldl, int64_t strideL, const void *E, int64_t lde,
+                                  const void *E2, int64_t lde2, const void *sigma, void *F,
+                                  int64_t ldf, void *Y, int64_t ldy) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_draw_batched: bad dtype %d", dtype);
+  GPVAE_REQUIRE(n >= 0, 3, "gpvae_draw_batched: n < 0");
+  GPVAE_REQUIRE(nb >= 0 && nb <= 65535, 4, "gpvae_draw_batched: nb out of range [0,65535]");
+  if (n == 0 || nb == 0) return 0;
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  GPVAE_REQUIRE(n * es <= 64 * 1024, 3, "gpvae_draw_batched: n too large (one row of normals must fit 64 KB of LDS)");
+  GPVAE_REQUIRE(L, 5, "gpvae_draw_batched: L is NULL");
+  GPVAE_REQUIRE(ldl >= n, 6, "gpvae_draw_batched: ldl < n");
+  GPVAE_REQUIRE(nb == 1 || strideL >= n * ldl, 7, "gpvae_draw_batched: strideL < n*ldl");
+  GPVAE_REQUIRE(E, 8, "gpvae_draw_batched: E is NULL");
+  GPVAE_REQUIRE(lde >= n, 9, "gpvae_draw_batched: lde < n");
+  if (E2) {
+    GPVAE_REQUIRE(lde2 >= n, 11, "gpvae_draw_batched: lde2 < n");
+    GPVAE_REQUIRE(sigma, 12, "gpvae_draw_batched: sigma is NULL with E2 given");
+  }
+  GPVAE_REQUIRE(F || Y, 15, "gpvae_draw_batched: both F and Y are NULL");
+  if (F) GPVAE_REQUIRE(ldf >= n, 14, "gpvae_draw_batched: ldf < n");
+  if (Y) GPVAE_REQUIRE(ldy >= n, 16, "gpvae_draw_batched: ldy < n");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)cdiv(n, 64), (unsigned)nb);
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((draw_batched_kernel<float>), grid, dim3(NTHREADS), (size_t)(n * es), st, n,
+                       (const float *)L, ldl, strideL, (const float *)E, lde, (const float *)E2, lde2,
+                       (const float *)sigma, (float *)F, ldf, (float *)Y, ldy);
+  else
+    hipLaunchKernelGGL((draw_batched_kernel<double>), grid, dim3(NTHREADS), (size_t)(n * es), st, n,
+                       (const double *)L, ldl, strideL, (const double *)E, lde, (const double *)E2, lde2,
+                       (const double *)sigma, (double *)F, ldf, (double *)Y, ldy);
+  GPVAE_CHECK_LAUNCH("gpvae_draw_batched");
   return 0;
 }
 

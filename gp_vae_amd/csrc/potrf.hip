@@ -24,9 +24,14 @@ namespace gpvae {
 constexpr int NB = 64;     // inner (panel) block
 constexpr int NBO = 256;   // outer block
 
-// developer probe: when set (gpvae_dev_set_stamps), block (0,0) of the panel launch of column
-// block c0/64 writes s_memtime at its phase boundaries to stamps[8*(c0/64) + 0..7]
+// developer probe (make DEV=1 builds only): when set (gpvae_dev_set_stamps), block (0,0) of the panel
+// launch of column block c0/64 writes s_memtime at its phase boundaries to stamps[8*(c0/64) + 0..7].
+// The product build has no such global: the kernel's stamp pointer is a constant nullptr.
+#ifdef GPVAE_DEV
 static unsigned long long *g_stamps = nullptr;
+#else
+static constexpr unsigned long long *g_stamps = nullptr;
+#endif
 #define STAMP(i)                                                                   \
   do {                                                                             \
     if (stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)       \
@@ -671,7 +676,9 @@ static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda,
 
 using namespace gpvae;
 
+#ifdef GPVAE_DEV
 extern "C" void gpvae_dev_set_stamps(void *p) { gpvae::g_stamps = (unsigned long long *)p; }
+#endif
 
 extern "C" int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch) {
   (void)m_extra;

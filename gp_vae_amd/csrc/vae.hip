@@ -831,6 +831,42 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
   return 0;
 }
 
+// sd = exp(log sd) in place; Z = MU + sd * eps when eps and Z are given (the guide's sample, vae.py:135)
+template <typename T>
+__global__ void exp_reparam_kernel(int64_t count, const T *__restrict__ MU, T *SD,
+                                   const T *__restrict__ eps, T *Z) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const T sd = dexp<T>(SD[i]);
+  SD[i] = sd;
+  if (Z != nullptr) Z[i] = MU[i] + sd * eps[i];
+}
+
+// encoder alone (vae_encoder's apply, vae.py:72-85; the guide's z, vae.py:134-135): four dense layers
+// as tile products with fused bias / relu epilogues + one elementwise kernel
+template <typename T>
+static int run_encoder(hipStream_t st, int64_t B, int64_t n, int h0, int h1, int z,
+                       const void *params_v, const void *Y_v, int64_t ldy, const void *eps_v,
+                       void *MU_v, void *SD_v, void *Z_v, void *work_v) {
+  VaeParams<T> P((const T *)params_v, n, h0, h1, z);
+  T *H1 = (T *)work_v, *H2 = H1 + B * h0;
+  {
+    GemmArgs<T> g{};
+    g.A = (const T *)Y_v; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = H1; g.ldc = h0;
+    g.M = B; g.N = h0; g.K = n; g.bias = P.b1; g.relu = 1;
+    g.vec_a = kc_vec_ok<T>(Y_v, ldy); g.vec_b = mc_vec_ok<T>(P.W1, h0);
+    launch_gemm<T, true, false, EPI_FUSED>(st, g, 1);
+  }
+  dense_gemm<T>(st, H1, B, h0, P.W2, h1, P.b2, 1, H2);
+  dense_gemm<T>(st, H2, B, h1, P.Wmu, z, P.bmu, 0, (T *)MU_v);
+  dense_gemm<T>(st, H2, B, h1, P.Wsd, z, P.bsd, 0, (T *)SD_v);
+  const int64_t Bz = B * z;
+  hipLaunchKernelGGL((exp_reparam_kernel<T>), dim3((unsigned)cdiv(Bz, 256)), dim3(256), 0, st, Bz,
+                     (const T *)MU_v, (T *)SD_v, (const T *)eps_v, (T *)Z_v);
+  GPVAE_CHECK_LAUNCH("gpvae_encoder_fwd");
+  return 0;
+}
+
 }  // namespace gpvae
 
 using namespace gpvae;
@@ -900,6 +936,29 @@ extern "C" int gpvae_adam(void *stream, int dtype, int64_t count, void *params, 
                        b2, eps, c1, c2);
   GPVAE_CHECK_LAUNCH("gpvae_adam");
   return 0;
+}
+
+extern "C" int64_t gpvae_encoder_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1,
+                                                 int z) {
+  (void)n; (void)z;
+  return B * ((int64_t)h0 + (int64_t)h1) * (dtype == GPVAE_F64 ? 8 : 4) + 256;
+}
+
+extern "C" int gpvae_encoder_fwd(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,
+                                 const void *enc_params, const void *Y, int64_t ldy,
+                                 const void *eps_z, void *mu, void *sd, void *Z, void *work) {
+  if (int rc = check_dims("gpvae_encoder_fwd", dtype, B, n, h0, h1, z)) return rc;
+  if (B == 0) return 0;
+  GPVAE_REQUIRE(enc_params, 8, "gpvae_encoder_fwd: enc_params is NULL");
+  GPVAE_REQUIRE(Y, 9, "gpvae_encoder_fwd: Y is NULL");
+  GPVAE_REQUIRE(ldy >= n, 10, "gpvae_encoder_fwd: ldy < n");
+  GPVAE_REQUIRE(mu && sd, 12, "gpvae_encoder_fwd: mu / sd is NULL");
+  GPVAE_REQUIRE((Z == nullptr) || eps_z, 11, "gpvae_encoder_fwd: Z wanted but eps_z is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 15, "gpvae_encoder_fwd: work is NULL or not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32
+             ? run_encoder<float>(st, B, n, h0, h1, z, enc_params, Y, ldy, eps_z, mu, sd, Z, work)
+             : run_encoder<double>(st, B, n, h0, h1, z, enc_params, Y, ldy, eps_z, mu, sd, Z, work);
 }
 
 extern "C" int64_t gpvae_decoder_workspace_bytes(int dtype, int64_t chains, int64_t n, int h0,

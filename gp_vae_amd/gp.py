@@ -48,6 +48,27 @@ def _seed_of(rng_key):
     return s
 
 
+class PhiloxKey():
+    """A counter-based key: (seed, stream base).  A consumer derives its Philox stream ids as
+    base | purpose (purpose 1: eps, 2: eps', 3: eps_z; parallel.philox_stream_id packs rank, epoch key
+    and step into the base), so the literal Predictive -> SVI.update loop and the pipelined
+    StepEngine draw the same normals for the same step."""
+
+    def __init__(self, seed, base=0):
+        self.seed = int(seed) & (2 ** 63 - 1)
+        self.base = int(base) & ~0xF & (2 ** 64 - 1)
+
+    def stream(self, purpose):
+        return self.base | (purpose & 0xF)
+
+
+def _key_parts(rng_key):
+    """(seed, stream base) of any accepted key."""
+    if isinstance(rng_key, PhiloxKey):
+        return rng_key.seed, rng_key.base
+    return _seed_of(rng_key), 0
+
+
 def agg_kernel_grid(rng_key, d, m, kernel, var, ls, grid1, grid2=None, jitter=1.0e-6):
     """Cell-averaged kernel over a [0,1]^d grid (gp.py:85-127).
 
@@ -99,17 +120,17 @@ class GP():
         'noise']} with a leading [num_samples] axis."""
         x = _as_device(x)
         n = x.shape[0]
-        seed = _seed_of(rng_key)
+        seed, base = _key_parts(rng_key)
         B = int(num_samples)
-        E = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=1)
-        E2 = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=2)
+        E = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=base | 1)
+        E2 = ops.randn((B, n), x.dtype, x.device, seed=seed, stream_id=base | 2)
         out = {}
         if ls is not None and var is not None and sigma is not None:
             K = self.kernel(x, x, var, ls, self.jitter)
-            ops.potrf_(K)
+            self.last_info = ops.potrf_(K)
             F, Y = ops.draw(K, E, E2, sigma, want_f=True)
         else:
-            rng = np.random.default_rng(seed)
+            rng = np.random.default_rng(seed if base == 0 else [seed, base])
             ls_s, var_s, sig_s = draw_hyper(rng, B)
             if ls is not None:
                 ls_s = np.full(B, float(ls))
@@ -125,28 +146,45 @@ class GP():
                 out["noise"] = torch.as_tensor(sig_s, dtype=x.dtype, device=x.device)
             if self.kernel is not exp_kernel2:
                 raise NotImplementedError("per-sample hyper-parameters need the built-in kernel")
-            Kb = ops.gram_se(x, x, torch.as_tensor(var_s, dtype=x.dtype, device=x.device),
-                             torch.as_tensor(ls_s, dtype=x.dtype, device=x.device), self.jitter)
-            Kb = Kb.reshape(B, n, n)
-            ops.potrf_(Kb)  # B distinct factors in one batched sweep
+            var_t = torch.as_tensor(var_s, dtype=x.dtype, device=x.device)
+            ls_t = torch.as_tensor(ls_s, dtype=x.dtype, device=x.device)
+            sig_t = torch.as_tensor(sig_s, dtype=x.dtype, device=x.device)
             F = torch.empty((B, n), dtype=x.dtype, device=x.device)
             Y = torch.empty((B, n), dtype=x.dtype, device=x.device)
-            for b in range(B):
-                f_b, y_b = ops.draw(Kb[b], E[b:b + 1], E2[b:b + 1], float(sig_s[b]), want_f=True)
-                F[b], Y[b] = f_b[0], y_b[0]
+            # B distinct K/L (gp.py:171-176 under Predictive): batched Gram, ONE batched factor sweep
+            # and one batched-factor draw per chunk of samples; chunks bound the factors to ~2 GiB
+            per = max(1, min(B, int(2 ** 31 // max(1, n * n * x.element_size()))))
+            infos = []
+            for lo in range(0, B, per):
+                hi = min(B, lo + per)
+                Kb = ops.gram_se(x, x, var_t[lo:hi], ls_t[lo:hi], self.jitter)
+                Kb = Kb.reshape(hi - lo, n, n)
+                infos.append(ops.potrf_(Kb))
+                f_c, y_c = ops.draw_batched(Kb, E[lo:hi], E2[lo:hi], sig_t[lo:hi], want_f=True)
+                F[lo:hi], Y[lo:hi] = f_c, y_c
+            self.last_info = torch.cat(infos)
         out["f"] = F
         out["y"] = Y if y is None else _as_device(y, x.dtype).expand(B, n)
         return out
 
 
 class Predictive():
-    """Call-compatible stand-in for numpyro.infer.Predictive(model, num_samples=...) applied to
-    GP.sample (vae.py:223, toy_examples.py:88): `Predictive(gp.sample, num_samples=B)(rng_key, x=x,
-    ls=..., var=..., sigma=...)` -> {'y': [B,n], 'f': [B,n], ...}."""
+    """Call-compatible stand-in for numpyro.infer.Predictive at the reference's call sites:
+      Predictive(gp.sample, num_samples=B)(rng_key, x=x, ls=..., var=..., sigma=...) -> {'y': [B,n], 'f', ...}
+                                                          (vae.py:223-226,160-162; toy_examples.py:88)
+      Predictive(inference.regression, num_samples=1000)(rng_key)["y_pred"]      (inference.py:113-114,502-503)
+      Predictive(inference.regression, post_samples)(rng_key)["y_pred"]          (inference.py:119-120)
+    The model is a method of this package that vectorises itself over draws: it is called once with
+    rng_key= and num_samples= (or posterior_samples=) added to the caller's arguments."""
 
-    def __init__(self, model, num_samples):
+    def __init__(self, model, posterior_samples=None, num_samples=None):
+        if posterior_samples is None and num_samples is None:
+            raise ValueError("Predictive: give num_samples or posterior_samples")
         self.model = model
+        self.posterior_samples = posterior_samples
         self.num_samples = num_samples
 
     def __call__(self, rng_key, *args, **kwargs):
+        if self.posterior_samples is not None:
+            return self.model(*args, rng_key=rng_key, posterior_samples=self.posterior_samples, **kwargs)
         return self.model(*args, rng_key=rng_key, num_samples=self.num_samples, **kwargs)

@@ -17,12 +17,17 @@ import torch
 
 
 def hmc(potential_and_grad, q0, num_warmup, num_samples, thinning=1, num_leapfrog=16, step_size=0.05,
-        target_accept=0.8, seed=0):
+        target_accept=0.8, seed=0, noise_fn=None):
     """potential_and_grad(q [C, D]) -> (U [C], dU/dq [C, D]).  q0: [C, D] initial positions.
 
     Returns (samples [num_samples // thinning, C, D], info) where info holds the mean acceptance
     probability per chain over the sampling phase, the adapted step sizes and the number of
-    divergent (non-finite energy) proposals."""
+    divergent (non-finite energy) proposals.
+
+    noise_fn (optional): noise_fn(it) -> (momenta [C, D], uniforms [C]) for iteration `it`.  The
+    inference drivers pass one whose rows depend only on (seed, global chain id, it), so a chain's
+    trajectory does not depend on which other chains share its batch — chains sharded over ranks
+    reproduce the single-process run.  Default: one torch generator for the whole batch."""
     q = q0.clone()
     C, D = q.shape
     dev, dt = q.device, q.dtype
@@ -44,7 +49,11 @@ def hmc(potential_and_grad, q0, num_warmup, num_samples, thinning=1, num_leapfro
     for it in range(num_warmup + num_samples):
         warm = it < num_warmup
         eps = torch.exp(log_eps if warm else log_eps_bar)[:, None]
-        p = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
+        if noise_fn is None:
+            p = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
+            unif = torch.rand(C, dtype=dt, device=dev, generator=gen)
+        else:
+            p, unif = noise_fn(it)
         h0 = U + 0.5 * (p * p).sum(1)
         qn, gn = q, g
         pn = p - 0.5 * eps * gn
@@ -59,7 +68,7 @@ def hmc(potential_and_grad, q0, num_warmup, num_samples, thinning=1, num_leapfro
         bad = ~torch.isfinite(dh)
         divergent += int(bad.sum().item())
         a = torch.where(bad, torch.zeros_like(dh), torch.exp(torch.clamp(dh, max=0.0)))
-        take = torch.rand(C, dtype=dt, device=dev, generator=gen) < a
+        take = unif < a
         q = torch.where(take[:, None], qn, q)
         g = torch.where(take[:, None], gn, g)
         U = torch.where(take, Un, U)

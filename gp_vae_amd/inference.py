@@ -19,9 +19,24 @@ import torch.distributed as dist
 from . import ops
 from .hmc import hmc
 from ._lib import GpvaeError
-from .gp import _as_device, _seed_of, exp_kernel2
-from .parallel import shard
+from .gp import _as_device, _key_parts, _seed_of, exp_kernel2
+from .parallel import dist_info, shard
 from .vae import decoder_flat_from_list
+
+
+class Potential():
+    """What NUTS/HMC needs of a NumPyro model conditioned on data: the potential energy in the
+    unconstrained space and its gradient for a batch of chains (`__call__(q [C, dim]) -> (U [C],
+    dU/dq [C, dim])`), a start point (`init`, the init_to_median of inference.py:84,477) and the map
+    from unconstrained rows back to the model's sites (`unpack`).  Returned by the `regression` /
+    `gp_regression` methods when they are called with data, i.e. where the reference hands the model
+    function to NUTS."""
+
+    def __init__(self, fn, init, unpack):
+        self.fn, self.init, self.unpack = fn, init, unpack
+
+    def __call__(self, q):
+        return self.fn(q)
 
 
 class Inference():
@@ -46,26 +61,50 @@ class Inference():
     def regression(self, y=None, obs_idx=None):
         raise NotImplementedError  # inference.py:63-66
 
-    def _mcmc(self, rng_key, potential, q0):
+    def _mcmc(self, rng_key, potential, q0=None):
         """mcmc_args of the reference (num_warmup, num_samples, num_chains, thinning;
         inference.py:86-93) driving the batched HMC of gp_vae_amd.hmc (NUTS is third-party code
         that is absent here — same target, different trajectory rule).  q0: [dim] start, jittered
-        per chain.  Returns samples [num_samples // thinning * num_chains, dim] (chains
-        concatenated, as mcmc.get_samples() does) and the sampler's info dict."""
+        per chain.  With torch.distributed initialised the chains are sharded round-robin over the
+        ranks (no collective; chain c keeps its start point and its own random
+        stream whatever the world size) and each rank returns its own chains' samples
+        [num_samples // thinning * local_chains, dim], chains concatenated as mcmc.get_samples()
+        does; the host concatenates ranks if it wants all of them."""
         a = self.mcmc_args
         chains = int(a.get("num_chains", 1))
-        gen = torch.Generator(device=q0.device)
-        gen.manual_seed(_seed_of(rng_key))
-        start = q0[None, :] + 0.01 * torch.randn((chains, q0.numel()), dtype=q0.dtype, device=q0.device,
-                                                  generator=gen)
+        if q0 is None:
+            q0 = potential.init
+        mine = list(shard(chains))
+        self.chain_ids = mine
+        seed = _seed_of(rng_key)
+        if not mine:
+            self.mcmc_info = {}
+            return q0.new_empty((0, q0.numel())), {}
+        rows0 = torch.as_tensor(mine, dtype=torch.long, device=q0.device)
+        start = q0[None, :] + 0.01 * ops.randn((chains, q0.numel()), q0.dtype, q0.device, seed=seed,
+                                               stream_id=0x1417 << 32)[rows0]
+        rows = torch.as_tensor(mine, dtype=torch.long, device=q0.device)
+        D = q0.numel()
+
+        def noise_fn(it):
+            # Philox rows of ALL chains, this rank keeps its own: element (chain c, j) of iteration `it`
+            # is the same number on any world size
+            g = ops.randn((chains, D + 1), q0.dtype, q0.device, seed=seed + 1, stream_id=(0x1418 << 32) | it)[rows]
+            unif = 0.5 * (1.0 + torch.erf(g[:, D] * (1.0 / math.sqrt(2.0))))
+            return g[:, :D], unif
+
         smp, info = hmc(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
                         thinning=int(a.get("thinning", 1)), num_leapfrog=int(a.get("num_leapfrog", 16)),
-                        seed=_seed_of(rng_key) + 1)
+                        seed=seed + 1, noise_fn=noise_fn)
         self.mcmc_info = info
         return smp.permute(1, 0, 2).reshape(-1, q0.numel()), info
 
     def run_mcmc(self, rng_key):
-        raise NotImplementedError  # the subclasses know their model (inference.py:69-99)
+        """Posterior samples of self.regression given (self.y, self.obs_idx) (inference.py:69-99):
+        the dict mcmc.get_samples() returns, one entry per sample site."""
+        pot = self.regression(y=self.y, obs_idx=self.obs_idx)
+        smp, _ = self._mcmc(rng_key, pot)
+        return pot.unpack(smp)
 
 
 class GPInference(Inference):
@@ -77,81 +116,155 @@ class GPInference(Inference):
             raise NotImplementedError("GPInference is built for exp_kernel2")
         self.kernel = kernel
 
-    def _split(self):
-        n = self.x.shape[0]
-        mask = torch.ones(n, dtype=torch.bool, device=self.x.device)
+    def _split(self, x=None):
+        x = self.x if x is None else x
+        n = x.shape[0]
+        mask = torch.ones(n, dtype=torch.bool, device=x.device)
         mask[self.obs_idx] = False
         test_idx = torch.nonzero(mask).reshape(-1)  # jnp.delete(x, obs_idx, axis=0)  inference.py:442
-        return self.x[self.obs_idx].contiguous(), self.x[test_idx].contiguous()
+        return x[self.obs_idx].contiguous(), x[test_idx].contiguous()
 
     def gp_prediction(self, rng_key, x, y, var, ls, sigma, return_var=False):
         """Posterior mean and one posterior sample at the unobserved locations (inference.py:427-460).
         `rng_key` seeds the standard normals of the sample (Philox stream)."""
-        if x is not self.x:
-            self.x = _as_device(x, self.dtype)
+        x = self.x if x is self.x else _as_device(x, self.dtype)  # a local: self.x stays what it was
         y = _as_device(y, self.dtype)
-        x_obs, x_test = self._split()
-        xi = ops.randn((x_test.shape[0],), self.dtype, self.x.device, seed=_seed_of(rng_key),
+        x_obs, x_test = self._split(x)
+        xi = ops.randn((x_test.shape[0],), self.dtype, x.device, seed=_seed_of(rng_key),
                        stream_id=0xC41)
         mean, sample, var_out, info = ops.krig_predict(x_obs, x_test, y[self.obs_idx], var, ls,
                                                        sigma, 1.0e-5, xi)
         self.last_info = info
         return (mean, sample, var_out) if return_var else (mean, sample)
 
-    def potential_and_grad(self, f, log_var, log_ls, log_sigma):
-        """Potential energy of gp_regression (inference.py:400-424) in NumPyro's unconstrained space
-        and its gradient, for a batch of chains — what NUTS evaluates per leapfrog step.
-
+    def _gp_potential(self, x_pts, y_lik, lik_idx, f, log_var, log_ls, log_sigma):
+        """Potential of the latent-f GP model on the points x_pts with a Gaussian likelihood on
+        f[lik_idx] (None: every point), in NumPyro's unconstrained space, and its gradient.
         sites: kernel_var ~ LogNormal(0,0.1), kernel_sigma ~ HalfNormal(0.1),
-               kernel_length ~ InverseGamma(4,1), f ~ MVN(0, kernel(x_obs, x_obs, var, ls)),
-               y_pred ~ Normal(f, sigma) observed at x_obs.
-        f: [chains, n_obs]; log_var, log_ls, log_sigma: [chains].
-        Returns (U [chains], dU/df [chains, n_obs], dU/dlog_var, dU/dlog_ls, dU/dlog_sigma).
+               kernel_length ~ InverseGamma(4,1), f ~ MVN(0, kernel(x, x, var, ls)),
+               y ~ Normal(f[lik_idx], sigma) observed.       (inference.py:368-396, 407-424)
         The MVN term and its gradient are one gpvae_mvn_logp call; the priors and the Gaussian
-        likelihood are O(chains * n_obs) glue."""
-        x_obs = self.x[self.obs_idx].contiguous()
-        y_obs = self.y[self.obs_idx]
-        n = x_obs.shape[0]
+        likelihood are O(chains * n) glue."""
+        n = x_pts.shape[0]
         f = _as_device(f, self.dtype).reshape(-1, n).contiguous()
         uv, ul, us = (_as_device(t, self.dtype).reshape(-1) for t in (log_var, log_ls, log_sigma))
         var, ls, sig = torch.exp(uv), torch.exp(ul), torch.exp(us)
-        lp, gf, gv, gl, info = ops.mvn_logp(x_obs, f, var, ls, 1.0e-5)
+        lp, gf, gv, gl, info = ops.mvn_logp(x_pts, f, var, ls, 1.0e-5)
         self.last_info = info
         s0, hl2p = 0.1, 0.5 * math.log(2 * math.pi)
-        r = (y_obs[None, :] - f) / sig[:, None]
+        f_lik = f if lik_idx is None else f[:, lik_idx]
+        m = f_lik.shape[1]
+        r = (y_lik[None, :] - f_lik) / sig[:, None]
         sq = (r * r).sum(1)
         logp = (-math.log(s0) - hl2p - uv ** 2 / (2 * s0 ** 2)) \
             + (math.log(2.0) - hl2p - math.log(s0) - 0.5 * (sig / s0) ** 2 + us) \
             + (-math.lgamma(4.0) - 4.0 * ul - 1.0 / ls) \
-            + lp + (-0.5 * sq - n * us - n * hl2p)
-        d_f = gf + r / sig[:, None]
+            + lp + (-0.5 * sq - m * us - m * hl2p)
+        if lik_idx is None:
+            d_f = gf + r / sig[:, None]
+        else:
+            d_f = gf.clone()
+            d_f[:, lik_idx] += r / sig[:, None]
         d_uv = -uv / s0 ** 2 + gv * var
         d_ul = -4.0 + 1.0 / ls + gl * ls
-        d_us = 1.0 - (sig / s0) ** 2 + sq - n
+        d_us = 1.0 - (sig / s0) ** 2 + sq - m
         return -logp, -d_f, -d_uv, -d_ul, -d_us
 
-    def gp_run_mcmc(self, rng_key):
-        """Posterior samples of gp_regression at the observed points (inference.py:463-490):
-        dict with kernel_var, kernel_sigma, kernel_length [S] and f [S, n_obs]."""
-        n = int(self.obs_idx.numel())
+    def potential_and_grad(self, f, log_var, log_ls, log_sigma):
+        """Potential energy of gp_regression (inference.py:400-424) at the observed points and its
+        gradient, for a batch of chains — what NUTS evaluates per leapfrog step.
+        f: [chains, n_obs]; log_var, log_ls, log_sigma: [chains].
+        Returns (U [chains], dU/df [chains, n_obs], dU/dlog_var, dU/dlog_ls, dU/dlog_sigma)."""
+        x_obs = self.x[self.obs_idx].contiguous()
+        return self._gp_potential(x_obs, self.y[self.obs_idx], None, f, log_var, log_ls, log_sigma)
+
+    def _latent_gp_model(self, x_pts, y_lik, lik_idx):
+        """The Potential of the latent-f model: unconstrained vector q = (f [n], log var, log ls,
+        log sigma)."""
+        n = x_pts.shape[0]
         # init_to_median of the priors: var 1, ls median of InverseGamma(4,1), sigma median of HalfNormal(.1)
         q0 = torch.zeros(n + 3, dtype=self.dtype, device=self.x.device)
         q0[n + 1] = math.log(0.2723)
         q0[n + 2] = math.log(0.0674)
 
-        def potential(q):
-            U, dF, dV, dL, dS = self.potential_and_grad(q[:, :n], q[:, n], q[:, n + 1], q[:, n + 2])
+        def fn(q):
+            U, dF, dV, dL, dS = self._gp_potential(x_pts, y_lik, lik_idx, q[:, :n], q[:, n], q[:, n + 1],
+                                                   q[:, n + 2])
             return U, torch.cat([dF, dV[:, None], dL[:, None], dS[:, None]], 1)
 
-        smp, _ = self._mcmc(rng_key, potential, q0)
-        return {"f": smp[:, :n], "kernel_var": torch.exp(smp[:, n]), "kernel_length": torch.exp(smp[:, n + 1]),
-                "kernel_sigma": torch.exp(smp[:, n + 2])}
+        def unpack(smp):
+            return {"f": smp[:, :n], "kernel_var": torch.exp(smp[:, n]),
+                    "kernel_length": torch.exp(smp[:, n + 1]), "kernel_sigma": torch.exp(smp[:, n + 2])}
+
+        return Potential(fn, q0, unpack)
+
+    def _predictive_draws(self, x_pts, rng_key, num_samples, posterior_samples):
+        """y_pred ~ Normal(f, sigma) with f ~ MVN(0, kernel(x, x, var, ls)) per draw (the y=None branch,
+        inference.py:386-389), hyper-parameters from the priors or from posterior samples."""
+        seed, base = _key_parts(rng_key)
+        dev, dt = self.x.device, self.dtype
+        if posterior_samples is not None:
+            var = torch.as_tensor(posterior_samples["kernel_var"], dtype=dt, device=dev).reshape(-1)
+            ls = torch.as_tensor(posterior_samples["kernel_length"], dtype=dt, device=dev).reshape(-1)
+            sig = torch.as_tensor(posterior_samples["kernel_sigma"], dtype=dt, device=dev).reshape(-1)
+        else:
+            rng = np.random.default_rng(seed if base == 0 else [seed, base])
+            S = int(num_samples)
+            var = torch.as_tensor(np.exp(0.1 * rng.standard_normal(S)), dtype=dt, device=dev)   # LogNormal(0,.1)
+            sig = torch.as_tensor(np.abs(0.1 * rng.standard_normal(S)), dtype=dt, device=dev)   # HalfNormal(.1)
+            ls = torch.as_tensor(1.0 / rng.gamma(4.0, size=S), dtype=dt, device=dev)            # InverseGamma(4,1)
+        S, n = var.numel(), x_pts.shape[0]
+        E = ops.randn((S, n), dt, dev, seed=seed, stream_id=base | 1)
+        E2 = ops.randn((S, n), dt, dev, seed=seed, stream_id=base | 2)
+        F = torch.empty((S, n), dtype=dt, device=dev)
+        Y = torch.empty((S, n), dtype=dt, device=dev)
+        per = max(1, min(S, int(2 ** 31 // max(1, n * n * x_pts.element_size()))))
+        for lo in range(0, S, per):
+            hi = min(S, lo + per)
+            Kb = ops.gram_se(x_pts, x_pts, var[lo:hi], ls[lo:hi], 1.0e-5).reshape(hi - lo, n, n)
+            ops.potrf_(Kb)
+            F[lo:hi], Y[lo:hi] = ops.draw_batched(Kb, E[lo:hi], E2[lo:hi], sig[lo:hi], want_f=True)
+        return {"kernel_var": var, "kernel_sigma": sig, "kernel_length": ls, "f": F, "y_pred": Y}
+
+    def regression(self, y=None, obs_idx=None, rng_key=None, num_samples=None, posterior_samples=None):
+        """GP regression model on the whole grid (inference.py:359-397).
+        With data (`y`, `obs_idx`; NaN allowed at unobserved entries of y): the :class:`Potential` NUTS
+        would be given.  Without (`y=None`, the prediction branch): a dict of draws with 'y_pred' —
+        what Predictive(self.regression, num_samples | posterior_samples)(rng_key) returns."""
+        if y is None:
+            return self._predictive_draws(self.x, rng_key, num_samples or 1, posterior_samples)
+        idx = self.obs_idx if obs_idx is None else torch.as_tensor(np.asarray(obs_idx), dtype=torch.long,
+                                                                    device=self.x.device)
+        yy = _as_device(y, self.dtype)
+        return self._latent_gp_model(self.x, yy[idx], idx)
+
+    def gp_regression(self, x, y=None, rng_key=None, num_samples=None, posterior_samples=None):
+        """Kriging / exact GP regression model at the observed locations x (inference.py:400-424):
+        with y the :class:`Potential` of (f, kernel_var, kernel_length, kernel_sigma); with y=None
+        prior / posterior predictive draws at x."""
+        xx = x if (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == self.dtype) else _as_device(x, self.dtype)
+        xx = ops._points(xx)
+        if y is None:
+            return self._predictive_draws(xx, rng_key, num_samples or 1, posterior_samples)
+        return self._latent_gp_model(xx, _as_device(y, self.dtype).reshape(-1), None)
+
+    def gp_run_mcmc(self, rng_key, x=None, y=None, model=None):
+        """Posterior samples of `model` (default self.gp_regression) given the observed (x, y)
+        (inference.py:463-490): dict with kernel_var, kernel_sigma, kernel_length [S] and f [S, n_obs]."""
+        x = self.x[self.obs_idx] if x is None else x
+        y = self.y[self.obs_idx] if y is None else y
+        pot = (self.gp_regression if model is None else model)(x, y)
+        if not isinstance(pot, Potential):
+            raise NotImplementedError("gp_run_mcmc: `model` must be GPInference.gp_regression (or return a "
+                                      "Potential); arbitrary NumPyro models need NumPyro")
+        smp, _ = self._mcmc(rng_key, pot)
+        return pot.unpack(smp)
 
     def gp_fit(self, plot=False, rng_key=None):
         """MCMC over the GP hyper-parameters, then kriging per posterior draw (inference.py:493-549).
         Returns (means, predictions), each [S, n_test].  Plotting is out of scope."""
         key = _seed_of(self.seed if rng_key is None else rng_key)
-        post = self.gp_run_mcmc(key + 2)
+        post = self.gp_run_mcmc(key + 2, self.x[self.obs_idx], self.y[self.obs_idx], model=self.gp_regression)
         cpu = {k: v.detach().cpu().numpy() for k, v in post.items() if k != "f"}
         return self.gp_fit_from_samples(key + 3, cpu)
 
@@ -200,33 +313,49 @@ class VAEInference(Inference):
         self.h1, self.h0, self.n_out = V1.shape[1], V2.shape[1], V3.shape[1]
         self.dec_flat = decoder_flat_from_list(decoder_params, self.dtype)
 
-    def run_mcmc(self, rng_key):
-        """Posterior samples of VAEInference.regression (inference.py:69-99, 243-254): dict with
-        noise [S], z [S, z_dim] and the deterministic f [S, n] = decoder(z)."""
+    def regression(self, y=None, obs_idx=None, rng_key=None, num_samples=None, posterior_samples=None):
+        """Regression model with the decoder as prior (inference.py:235-254).
+        With data: the :class:`Potential` over q = (z [z_dim], log noise) NUTS would be given, whose
+        `unpack` adds the deterministic site f = decoder(z).  With y=None (prediction branch,
+        inference.py:248-249): dict of draws with 'y_pred' ~ Normal(decoder(z), noise), z and noise
+        from the priors (num_samples) or from posterior_samples."""
         zd = self.z_dim
-        q0 = torch.zeros(zd + 1, dtype=self.dtype, device=self.x.device)
+        dev, dt = self.x.device, self.dtype
+        if y is None:
+            seed, base = _key_parts(rng_key)
+            if posterior_samples is not None:
+                z = _as_device(posterior_samples["z"], dt).reshape(-1, zd)
+                noise = _as_device(posterior_samples["noise"], dt).reshape(-1)
+            else:
+                S = int(num_samples or 1)
+                z = ops.randn((S, zd), dt, dev, seed=seed, stream_id=base | 5)
+                noise = 0.1 * ops.randn((S,), dt, dev, seed=seed, stream_id=base | 6).abs()  # HalfNormal(0.1)
+            f = self.predict(z)
+            y_pred = f + noise[:, None] * ops.randn(tuple(f.shape), dt, dev, seed=seed, stream_id=base | 7)
+            return {"noise": noise, "z": z, "f": f, "y_pred": y_pred}
+        idx = self.obs_idx if obs_idx is None else torch.as_tensor(np.asarray(obs_idx), dtype=torch.long,
+                                                                    device=dev)
+        y_obs = _as_device(y, dt)[idx]
+        q0 = torch.zeros(zd + 1, dtype=dt, device=dev)
         q0[zd] = math.log(0.0674)  # median of HalfNormal(0.1)
 
-        def potential(q):
-            U, dz, du = self.potential_and_grad(q[:, :zd], q[:, zd])
+        def fn(q):
+            U, dz, du = self._potential(q[:, :zd], q[:, zd], y_obs, idx)
             return U, torch.cat([dz, du[:, None]], 1)
 
-        smp, _ = self._mcmc(rng_key, potential, q0)
-        z = smp[:, :zd].contiguous()
-        return {"z": z, "noise": torch.exp(smp[:, zd]), "f": self.predict(z)}
+        def unpack(smp):
+            z = smp[:, :zd].contiguous()
+            return {"z": z, "noise": torch.exp(smp[:, zd]), "f": self.predict(z)}
+
+        return Potential(fn, q0, unpack)
 
     def fit(self, plot=False, rng_key=None, num_prior=1000):
         """Prior and posterior predictive draws y_pred ~ Normal(decoder(z), noise)
         (inference.py:101-146).  Returns (prior_predictions [num_prior, n], predictions [S, n])."""
         key = _seed_of(self.seed if rng_key is None else rng_key)
-        dev, dt = self.x.device, self.dtype
-        zp = ops.randn((num_prior, self.z_dim), dt, dev, seed=key, stream_id=0xF17)
-        sp = 0.1 * ops.randn((num_prior,), dt, dev, seed=key, stream_id=0xF18).abs()  # HalfNormal(0.1)
-        fp = self.predict(zp)
-        prior = fp + sp[:, None] * ops.randn(tuple(fp.shape), dt, dev, seed=key, stream_id=0xF19)
-        post = self.run_mcmc(key + 2)
-        f = post["f"]
-        pred = f + post["noise"][:, None] * ops.randn(tuple(f.shape), dt, dev, seed=key + 3, stream_id=0xF1A)
+        prior = self.regression(rng_key=key, num_samples=num_prior)["y_pred"]          # inference.py:113-114
+        post = self.run_mcmc(key + 2)                                                   # inference.py:116
+        pred = self.regression(rng_key=key + 3, posterior_samples=post)["y_pred"]       # inference.py:119-120
         return prior, pred
 
     def predict(self, z):
@@ -242,13 +371,15 @@ class VAEInference(Inference):
                y[obs] ~ Normal(decoder(z)[obs], sigma).
         Returns (U [chains], dU/dz [chains, z_dim], dU/dlog_sigma [chains]).  The decoder forward and
         its vector-Jacobian product are the HIP kernels; the O(chains * n_obs) tail is glue."""
+        return self._potential(z, log_sigma, self.y[self.obs_idx], self.obs_idx)
+
+    def _potential(self, z, log_sigma, y_obs, obs_idx):
         z = _as_device(z, self.dtype).reshape(-1, self.z_dim).contiguous()
         u = _as_device(log_sigma, self.dtype).reshape(-1)
         sigma = torch.exp(u)
         f = ops.decoder_fwd(self.dec_flat, z, self.n_out, self.h0, self.h1)
-        y_obs = self.y[self.obs_idx]
-        r = f[:, self.obs_idx] - y_obs[None, :]
-        n_obs = self.obs_idx.numel()
+        r = f[:, obs_idx] - y_obs[None, :]
+        n_obs = obs_idx.numel()
         s0 = 0.1
         half_log_2pi = 0.5 * math.log(2 * math.pi)
         sq = (r * r).sum(1)
@@ -257,7 +388,7 @@ class VAEInference(Inference):
         log_ps = math.log(2.0) - half_log_2pi - math.log(s0) - 0.5 * (sigma / s0) ** 2 + u
         U = -(log_lik + log_pz + log_ps)
         dF = torch.zeros_like(f)
-        dF[:, self.obs_idx] = r / (sigma ** 2)[:, None]
+        dF[:, obs_idx] = r / (sigma ** 2)[:, None]
         dz = z + ops.decoder_vjp(self.dec_flat, z, dF, self.h0, self.h1)
         du = (sigma / s0) ** 2 - 1.0 + n_obs - sq / sigma ** 2
         return U, dz, du

@@ -195,6 +195,35 @@ def draw(L, E, E2=None, sigma=None, want_f=False):
     return (F, Y) if want_f else Y
 
 
+def draw_batched(L, E, E2=None, sigma=None, want_f=False):
+    """One draw per factor: Y[b] = L[b] E[b] (+ sigma[b]*E2[b]).  L [nb,n,n] lower factors, E/E2 [nb,n],
+    sigma [nb] (or a scalar).  Returns Y or (F, Y).  (Predictive(gp.sample) with sampled
+    hyper-parameters: vae.py:226, toy_examples.py:88.)"""
+    _dev(L, E, E2)
+    if L.dim() != 3 or L.shape[1] != L.shape[2] or L.stride(2) != 1:
+        raise GpvaeError("draw_batched: L must be [nb,n,n] with unit column stride")
+    nb, n = L.shape[0], L.shape[1]
+    if tuple(E.shape) != (nb, n) or E.stride(1) != 1 or E.dtype != L.dtype:
+        raise GpvaeError("draw_batched: E must be [nb,n], same dtype, unit column stride")
+    if E2 is not None and (E2.shape != E.shape or E2.stride(1) != 1 or E2.dtype != L.dtype):
+        raise GpvaeError("draw_batched: E2 must match E")
+    Y = torch.empty((nb, n), dtype=L.dtype, device=L.device)
+    F = torch.empty((nb, n), dtype=L.dtype, device=L.device) if want_f else None
+    sig = None
+    if E2 is not None:
+        sig = scalar(sigma, L)
+        if sig.numel() == 1:
+            sig = sig.expand(nb).contiguous()
+        if sig.numel() != nb:
+            raise GpvaeError("draw_batched: sigma needs one entry per factor")
+    lib = _lib.load()
+    check(lib.gpvae_draw_batched(_stream(), _dt(L), n, nb, _p(L), L.stride(1), L.stride(0), _p(E),
+                                 E.stride(0), _p(E2), E2.stride(0) if E2 is not None else 0, _p(sig),
+                                 _p(F), F.stride(0) if want_f else 0, _p(Y), Y.stride(0)),
+          "gpvae_draw_batched")
+    return (F, Y) if want_f else Y
+
+
 def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=None):
     """Philox4x32-10 / Box-Muller standard normals; element i depends only on (seed, stream_id, i)."""
     if out is None:
@@ -331,6 +360,30 @@ def vae_elbo(params, Y, eps_z, dims, obs_sigma=0.1, grads=None, loss=None, work=
                              _p(eps_z), float(obs_sigma), _p(loss), _p(grads), _p(work.buf)),
           "gpvae_vae_elbo")
     return loss
+
+
+def encoder_fwd(params, Y, dims, eps_z=None):
+    """(mu, sd[, z]) of the encoder (vae_encoder's apply, vae.py:72-85; z = mu + sd*eps_z is the guide's
+    sample, vae.py:135).  params: the flat vector (or its encoder head); Y [B,n]; eps_z [B,z] or None."""
+    _dev(params, Y, eps_z)
+    h0, h1, z = dims
+    B, n = Y.shape
+    if Y.stride(1) != 1:
+        raise GpvaeError("encoder_fwd: Y needs unit column stride")
+    head = n * h0 + h0 + h0 * h1 + h1 + 2 * (h1 * z + z)
+    if params.numel() < head or not params.is_contiguous() or params.dtype != Y.dtype:
+        raise GpvaeError("encoder_fwd: params too short for (n,h0,h1,z), not contiguous or wrong dtype")
+    if eps_z is not None and (tuple(eps_z.shape) != (B, z) or not eps_z.is_contiguous()):
+        raise GpvaeError("encoder_fwd: eps_z must be contiguous [B,z]")
+    mu = torch.empty((B, z), dtype=Y.dtype, device=Y.device)
+    sd = torch.empty_like(mu)
+    zz = torch.empty_like(mu) if eps_z is not None else None
+    lib = _lib.load()
+    work = torch.empty(lib.gpvae_encoder_workspace_bytes(_dt(Y), B, n, h0, h1, z), dtype=torch.uint8,
+                       device=Y.device)
+    check(lib.gpvae_encoder_fwd(_stream(), _dt(Y), B, n, h0, h1, z, _p(params), _p(Y), Y.stride(0),
+                                _p(eps_z), _p(mu), _p(sd), _p(zz), _p(work)), "gpvae_encoder_fwd")
+    return (mu, sd) if eps_z is None else (mu, sd, zz)
 
 
 def adam_(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):

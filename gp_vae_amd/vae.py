@@ -28,18 +28,134 @@ import torch.distributed as dist
 from . import _lib, ops
 from ._lib import GpvaeError, check
 from .ops import _dt, _p, _stream
-from .gp import Predictive, _as_device, _seed_of, draw_hyper
+from .gp import PhiloxKey, Predictive, _as_device, _key_parts, _seed_of, draw_hyper, exp_kernel2
 from .parallel import allreduce_sum_start, allreduce_wait, allreduce_sum_, dist_info, philox_stream_id, step_rng
 
 
 class SVIState():
-    """What numpyro's SVIState carries for this model: parameters, Adam moments, step count."""
+    """What numpyro's SVIState carries for this model: parameters, Adam moments, step count and the
+    key (`seed`) the per-update latent normals are derived from."""
 
-    def __init__(self, params, m=None, v=None, t=0):
+    def __init__(self, params, m=None, v=None, t=0, seed=0):
         self.params = params
         self.m = torch.zeros_like(params) if m is None else m
         self.v = torch.zeros_like(params) if v is None else v
         self.t = t
+        self.seed = int(seed)
+
+
+class Adam():
+    """numpyro.optim.Adam(step_size, b1=0.9, b2=0.999, eps=1e-8) (vae.py:212): the hyper-parameters
+    of gpvae_adam."""
+
+    def __init__(self, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        self.step_size, self.b1, self.b2, self.eps = float(step_size), float(b1), float(b2), float(eps)
+
+
+class Trace_ELBO():
+    """numpyro.infer.Trace_ELBO() as the reference uses it (vae.py:217): one particle."""
+
+    def __init__(self, num_particles=1):
+        if num_particles != 1:
+            raise NotImplementedError("gpvae_vae_elbo is the one-particle ELBO of vae.py:213-218")
+        self.num_particles = 1
+
+
+_SVI_STREAM = 0x5E1 << 44  # Philox stream base of SVI's own latent normals (update t -> base | t << 4)
+
+
+class SVI():
+    """Call-compatible stand-in for numpyro.infer.SVI(model, guide, optim, loss) at the reference's
+    call sites (vae.py:213-218, 228, 165, 194, 257): `init(key, batch) -> state`,
+    `update(state, batch) -> (state, loss)`, `evaluate(state, batch) -> loss`,
+    `get_params(state)["decoder$params"]`.
+
+    It is not a probabilistic-programming engine: `model` and `guide` must be the bound
+    `vae_model` / `vae_guide` of one :class:`VAE` — the program whose ELBO, gradient and Adam step
+    gpvae_vae_elbo / gpvae_adam compute.  Anything else raises.  `update` takes an EXTERNALLY supplied
+    batch [B, n]; with torch.distributed initialised the flat gradient is summed over ranks first (the
+    one collective of the path), so every rank applies the same step.  The state is updated in place
+    and returned."""
+
+    def __init__(self, model, guide, optim, loss, **static_kwargs):
+        vae = getattr(model, "__self__", None)
+        if (not isinstance(vae, VAE) or getattr(guide, "__self__", None) is not vae
+                or getattr(model, "__func__", None) is not VAE.vae_model
+                or getattr(guide, "__func__", None) is not VAE.vae_guide):
+            raise NotImplementedError("SVI here runs VAE.vae_model / VAE.vae_guide of one VAE object (the "
+                                      "ELBO gpvae_vae_elbo implements); other programs need NumPyro")
+        if not isinstance(optim, Adam):
+            raise NotImplementedError("SVI: the optimiser of this path is Adam (vae.py:212)")
+        if not isinstance(loss, Trace_ELBO):
+            raise NotImplementedError("SVI: the loss of this path is Trace_ELBO() (vae.py:217)")
+        if static_kwargs:
+            raise NotImplementedError("SVI: static model arguments are not part of this path")
+        self.vae, self.optim, self.loss = vae, optim, loss
+        self.model, self.guide = model, guide
+        self._grads = None
+        self._work = None
+
+    def _dims(self):
+        v = self.vae
+        return v.hidden_dims[0], v.hidden_dims[1], v.z_dim
+
+    def _batch(self, batch):
+        v = self.vae
+        Y = _as_device(batch, v.dtype)
+        Y = Y.reshape(Y.shape[0], -1)  # vae.py:107,129
+        if Y.shape[1] != v.out_dim:
+            raise GpvaeError("SVI: batch has %d columns, the VAE's out_dim is %d" % (Y.shape[1], v.out_dim))
+        return Y if Y.stride(1) == 1 else Y.contiguous()
+
+    def init(self, rng_key, batch):
+        """Fresh 1e-2*N(0,1) parameters (stax.randn, vae.py:76-95) keyed by rng_key, zero Adam moments.
+        The batch only fixes the shapes, as in numpyro.module's initialisation."""
+        self._batch(batch)
+        v = self.vae
+        seed = _seed_of(rng_key)
+        h0, h1, z = self._dims()
+        return SVIState(init_params(v.out_dim, h0, h1, z, seed, v.dtype, v.x.device), seed=seed)
+
+    def _eps(self, state, B, rng_key):
+        v = self.vae
+        if rng_key is None:
+            seed, base = state.seed, _SVI_STREAM | ((state.t + 1) << 4)
+        else:
+            seed, base = _key_parts(rng_key)
+        return ops.randn((B, v.z_dim), v.dtype, v.x.device, seed=seed, stream_id=base | 3)
+
+    def _elbo(self, state, batch, rng_key, train):
+        Y = self._batch(batch)
+        dims = self._dims()
+        if self._work is None or self._work.key != (Y.shape[0], Y.shape[1]) + dims + (Y.dtype,):
+            self._work = ops.VaeWorkspace(Y.shape[0], Y.shape[1], *dims, Y.dtype, Y.device)
+        if train and (self._grads is None or self._grads.numel() != state.params.numel()):
+            self._grads = torch.empty_like(state.params)
+        eps = self._eps(state, Y.shape[0], rng_key)
+        return ops.vae_elbo(state.params, Y, eps, dims, self.vae.obs_sigma,
+                            grads=self._grads if train else None, work=self._work)
+
+    def update(self, state, batch, rng_key=None):
+        """One step: loss = -ELBO(batch) and its gradient, [all-reduce], Adam (vae.py:165).
+        Returns (state, loss) with loss a device scalar [1].  rng_key (optional, a PhiloxKey) names the
+        latent normals; by default they follow the state's own key and step count."""
+        loss = self._elbo(state, batch, rng_key, True)
+        allreduce_sum_(self._grads)
+        state.t += 1
+        o = self.optim
+        ops.adam_(state.params, self._grads, state.m, state.v, state.t, o.step_size, o.b1, o.b2, o.eps)
+        return state, loss
+
+    def evaluate(self, state, batch, rng_key=None):
+        """loss = -ELBO(batch) at the current parameters, no update (vae.py:194)."""
+        return self._elbo(state, batch, rng_key, False)
+
+    def get_params(self, state):
+        """{'encoder$params', 'decoder$params'} in the stax list layouts (vae.py:257)."""
+        v = self.vae
+        h0, h1, z = self._dims()
+        return {"encoder$params": encoder_list_from_flat(state.params, v.out_dim, h0, h1, z),
+                "decoder$params": decoder_list_from_flat(state.params, v.out_dim, h0, h1, z)}
 
 
 def init_params(n, h0, h1, z, seed, dtype, device):
@@ -62,6 +178,27 @@ def decoder_list_from_flat(flat, n, h0, h1, z):
     return [(V1, c1), (), (V2, c2), (), (V3, c3)]
 
 
+def encoder_list_from_flat(flat, n, h0, h1, z):
+    """encoder$params as stax.serial(Dense, Relu, Dense, Relu, FanOut(2), parallel(Dense,
+    serial(Dense, Exp))) nests them (vae.py:75-85)."""
+    o = 0
+    W1 = flat[o:o + n * h0].reshape(n, h0); o += n * h0
+    b1 = flat[o:o + h0]; o += h0
+    W2 = flat[o:o + h0 * h1].reshape(h0, h1); o += h0 * h1
+    b2 = flat[o:o + h1]; o += h1
+    Wm = flat[o:o + h1 * z].reshape(h1, z); o += h1 * z
+    bm = flat[o:o + z]; o += z
+    Ws = flat[o:o + h1 * z].reshape(h1, z); o += h1 * z
+    bs = flat[o:o + z]
+    return [(W1, b1), (), (W2, b2), (), (), [(Wm, bm), [(Ws, bs), ()]]]
+
+
+def encoder_flat_from_list(params_list, dtype=None):
+    (W1, b1), _, (W2, b2), _, _, ((Wm, bm), ((Ws, bs), _)) = params_list
+    parts = [_as_device(a, dtype).reshape(-1) for a in (W1, b1, W2, b2, Wm, bm, Ws, bs)]
+    return torch.cat(parts).contiguous()
+
+
 def decoder_flat_from_list(params_list, dtype=None, device=None):
     (V1, c1), _, (V2, c2), _, (V3, c3) = params_list
     parts = [_as_device(a, dtype).reshape(-1) for a in (V1, c1, V2, c2, V3, c3)]
@@ -77,10 +214,16 @@ class StepEngine():
     draw/ELBO/Adam chain; 2 x group factor slots live in HBM (group=8, n=4096, f32: 1 GiB)."""
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
-                 hyper_sampler=draw_hyper, overlap=True, group=8):
-        self.x = _as_device(x, dtype)
+                 hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2):
+        if kernel is not exp_kernel2:
+            # the engine calls gpvae_gram_se itself: another kernel would silently train on SE
+            raise NotImplementedError("StepEngine builds its Gram matrices with gpvae_gram_se (exp_kernel2); "
+                                      "use VAE(..., pipelined=False) to train through an injected kernel")
+        # [n] or [n,d] row-major, as gpvae_gram_se reads it: a transposed / strided view (the 2-D
+        # scripts' array([u,v]).transpose idiom, 2d_examples.py:564) is copied, not reinterpreted
+        self.x = ops._points(_as_device(x, dtype))
         self.n = self.x.shape[0]
-        self.d = self.x.shape[1] if self.x.dim() == 2 else 1
+        self.d = self.x.shape[1]
         self.h0, self.h1, self.z = dims
         self.B = batch_size
         self.lr = lr
@@ -106,6 +249,7 @@ class StepEngine():
         self.hyper_dev = [torch.empty((3, G), dtype=dtype, device=dev) for _ in range(2)]  # var|ls|sigma
         self.hyper_pin = [torch.empty((3, G), dtype=dtype).pin_memory() for _ in range(2)]
         self.info = [torch.zeros(G, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.info_fail = torch.zeros(1, dtype=torch.int32, device=dev)  # factors reported not PD so far
         wbytes = _lib.load().gpvae_potrf_workspace_bytes(_dt(self.x), n, 0, G)
         self.pwork = [torch.empty(max(16, wbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.E = torch.empty((B, n), dtype=dtype, device=dev)
@@ -152,6 +296,7 @@ class StepEngine():
             check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
                                   0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
                   "gpvae_potrf")
+            self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
@@ -192,6 +337,14 @@ class StepEngine():
             state.t += 1
             ops.adam_(state.params, self.grads, state.m, state.v, state.t, self.lr)
 
+    def failed_factors(self):
+        """Number of Gram matrices gpvae_potrf reported as not positive definite since the engine was
+        built (synchronises).  Such a step trains on a NaN batch, as the reference's does (SURVEY.md
+        §2.1-11); fit() reports it with the epoch instead of leaving a bare NaN loss."""
+        if self.overlap:
+            self.s_gp.synchronize()
+        return int(self.info_fail.item())
+
     def run(self, keys, state, train=True):
         """Run the steps named by `keys` (tuples of ints feeding the per-step RNG streams).
         Returns the device scalar holding the summed loss of this rank."""
@@ -227,10 +380,16 @@ class StepEngine():
 
 
 class VAE():
-    """2-hidden-layer VAE trained on GP draws (reference constructor: vae.py:39-52)."""
+    """2-hidden-layer VAE trained on GP draws (reference constructor: vae.py:39-52).
+
+    `pipelined=True` (default) runs epoch_train / eval_test on :class:`StepEngine` (factor stream one
+    group ahead, batched factors); `pipelined=False` runs the reference's literal loop
+    draw hyper -> gp_predictive -> svi.update.  Same keys, same arithmetic, same results."""
+
+    obs_sigma = 0.1  # vae.py:117
 
     def __init__(self, gp, hidden_dims, z_dim, out_dim, batch_size, learning_rate, num_epochs,
-                 num_train, num_test, x, seed=0, dtype=torch.float32):
+                 num_train, num_test, x, seed=0, dtype=torch.float32, pipelined=True):
         self.gp = gp
         assert len(hidden_dims) == 2  # vae.py:55
         self.hidden_dims = hidden_dims
@@ -241,15 +400,40 @@ class VAE():
         self.num_epochs = num_epochs
         self.num_train = num_train
         self.num_test = num_test
-        self.x = _as_device(x, dtype)
+        x = _as_device(x, dtype)
+        self.x = x if x.is_contiguous() else x.contiguous()
         self.seed = seed
         self.dtype = dtype
+        self.pipelined = bool(pipelined)
         self.gp_predictive = None
+        self.svi = None
         self.engine = None
+        self.state = None
         self.test_loss_list = []
 
-    # stax-style (init, apply) pair: apply(params_list, z) -> decoder output (inference.py:246)
+    def _flat_dims(self):
+        return self.hidden_dims[0], self.hidden_dims[1], self.z_dim
+
+    # stax-style (init, apply) pairs -------------------------------------------------------------------
+    def vae_encoder(self):
+        """(init_fun, apply_fun) of the encoder (vae.py:72-85): apply(params, batch) -> (z_loc, z_std)."""
+        h0, h1, z = self._flat_dims()
+
+        def init_fun(rng_key, input_shape):
+            flat = init_params(self.out_dim, h0, h1, z, _seed_of(rng_key), self.dtype, self.x.device)
+            return ((z,), (z,)), encoder_list_from_flat(flat, self.out_dim, h0, h1, z)
+
+        def apply_fun(params, inputs, **kwargs):
+            flat = encoder_flat_from_list(params, self.dtype)
+            Y = _as_device(inputs, self.dtype)
+            single = Y.dim() == 1
+            mu, sd = ops.encoder_fwd(flat, Y.reshape(-1, self.out_dim).contiguous(), (h0, h1, z))
+            return (mu[0], sd[0]) if single else (mu, sd)
+
+        return init_fun, apply_fun
+
     def vae_decoder(self):
+        """(init_fun, apply_fun) of the decoder (vae.py:87-96): apply(params, z) -> f (inference.py:246)."""
         h0, h1 = self.hidden_dims
 
         def init_fun(rng_key, input_shape):
@@ -266,50 +450,128 @@ class VAE():
 
         return init_fun, apply_fun
 
+    def _params(self, params):
+        if params is not None:
+            return params
+        if self.state is None:
+            raise GpvaeError("vae_model / vae_guide outside SVI need parameters: pass params= or call "
+                             "fit() / svi.init() first")
+        return self.state.params
+
+    def vae_guide(self, batch, params=None, rng_key=None):
+        """Inference with the encoder (vae.py:120-137): z ~ Normal(z_loc, z_std), one row per sample.
+        `params`: flat parameter vector (default: the current SVI state's)."""
+        Y = _as_device(batch, self.dtype)
+        Y = Y.reshape(Y.shape[0], -1).contiguous()
+        seed, base = _key_parts(rng_key)
+        eps = ops.randn((Y.shape[0], self.z_dim), self.dtype, Y.device, seed=seed, stream_id=base | 3)
+        return ops.encoder_fwd(self._params(params), Y, self._flat_dims(), eps)[2]
+
+    def vae_model(self, batch, params=None, z=None, rng_key=None):
+        """Generation with the decoder (vae.py:98-117): z ~ N(0, I) (or the guide's z when replayed),
+        f = decoder(z), obs ~ Normal(f, 0.1) observed at `batch` — returns the observed site's value,
+        i.e. the batch, as numpyro.sample(..., obs=batch) does; f is kept in `self.last_f`."""
+        Y = _as_device(batch, self.dtype)
+        Y = Y.reshape(Y.shape[0], -1)
+        if z is None:
+            seed, base = _key_parts(rng_key)
+            z = ops.randn((Y.shape[0], self.z_dim), self.dtype, Y.device, seed=seed, stream_id=base | 4)
+        h0, h1, zd = self._flat_dims()
+        flat = self._params(params)
+        dec = flat[flat.numel() - (zd * h1 + h1 + h1 * h0 + h0 + h0 * self.out_dim + self.out_dim):]
+        self.last_f = ops.decoder_fwd(dec.contiguous(), _as_device(z, self.dtype).reshape(-1, zd),
+                                      self.out_dim, h0, h1)
+        return Y
+
+    # ---- training -------------------------------------------------------------------------------------
     def _engine(self):
         if self.engine is None:
             h0, h1 = self.hidden_dims
             self.engine = StepEngine(self.x, self.gp.jitter, (h0, h1, self.z_dim), self.batch_size,
-                                     self.learning_rate, self.dtype, self.seed)
+                                     self.learning_rate, self.dtype, self.seed, obs_sigma=self.obs_sigma,
+                                     kernel=self.gp.kernel)
         return self.engine
+
+    def _ensure_svi(self):
+        if self.svi is None:
+            self.svi = SVI(self.vae_model, self.vae_guide, Adam(self.learning_rate), Trace_ELBO())
+        if self.gp_predictive is None:
+            self.gp_predictive = Predictive(self.gp.sample, num_samples=self.batch_size)
+
+    def _literal_steps(self, keys, svi_state, train):
+        """The reference's loop body (vae.py:150-167 / 182-196), one step per key: draw
+        (ls, var, sigma), batch = gp_predictive(key, x, ls, var, sigma)['y'], svi.update / evaluate.
+        Keys, host RNG and Philox streams are the ones StepEngine uses."""
+        self._ensure_svi()
+        rank, _ = dist_info()
+        total = torch.zeros(1, dtype=self.dtype, device=self.x.device)
+        for key in keys:
+            ls, var, sigma = draw_hyper(step_rng(self.seed, rank, key))
+            pk = PhiloxKey(self.seed, philox_stream_id(rank, key, 0))
+            batch = self.gp_predictive(pk, self.x, ls=float(ls), var=float(var), sigma=float(sigma))
+            if train:
+                svi_state, loss = self.svi.update(svi_state, batch["y"], rng_key=pk)
+            else:
+                loss = self.svi.evaluate(svi_state, batch["y"], rng_key=pk)
+            total += loss
+        return total, svi_state
+
+    def _steps(self, keys, svi_state, train):
+        if self.pipelined:
+            return self._engine().run(keys, svi_state, train=train), svi_state
+        return self._literal_steps(keys, svi_state, train)
 
     def epoch_train(self, rng_key, svi_state):
         """num_train steps of draw-hyper -> GP batch -> svi.update (vae.py:139-169)."""
         k = _seed_of(rng_key) & 0x7FFFFFFF
-        loss = self._engine().run([(k, i) for i in range(self.num_train)], svi_state, train=True)
-        return loss, svi_state
+        return self._steps([(k, i) for i in range(self.num_train)], svi_state, True)
 
     def eval_test(self, rng_key, svi_state):
         """Mean per-sample test loss over num_test fresh batches (vae.py:172-201)."""
         k = _seed_of(rng_key) & 0x7FFFFFFF
-        loss = self._engine().run([(k, i) for i in range(self.num_test)], svi_state, train=False)
-        if self._engine().world > 1:
+        loss, _ = self._steps([(k, i) for i in range(self.num_test)], svi_state, False)
+        _, world = dist_info()
+        if world > 1:
             dist.all_reduce(loss, op=dist.ReduceOp.SUM)
-            loss = loss / self._engine().world
+            loss = loss / world
         return float(loss.item()) / self.batch_size / max(self.num_test, 1)
 
     def svi_init(self):
-        """svi.init (vae.py:228): fresh parameters, zero Adam moments; identical on every rank."""
-        h0, h1 = self.hidden_dims
-        return SVIState(init_params(self.out_dim, h0, h1, self.z_dim, self.seed, self.dtype,
-                                    self.x.device))
+        """svi.init (vae.py:228) with the VAE's own seed; identical on every rank."""
+        self._ensure_svi()
+        shape_only = torch.empty((self.batch_size, self.out_dim), dtype=self.dtype, device=self.x.device)
+        return self.svi.init(self.seed, shape_only)
 
     def fit(self, plot_loss=False):
         """Train (vae.py:203-257).  Returns svi.get_params(state)['decoder$params']."""
+        self.svi = SVI(self.vae_model, self.vae_guide, Adam(self.learning_rate), Trace_ELBO())
         self.gp_predictive = Predictive(self.gp.sample, num_samples=self.batch_size)
-        state = self.svi_init()
+        n = self.x.shape[0]
+        if self.batch_size * n * n * self.x.element_size() <= 2 ** 30:
+            # initialise with a sample batch (vae.py:226): batch_size GPs with their own hyper-parameters
+            sample_batch = self.gp_predictive(rng_key=PhiloxKey(self.seed, 0x1A17 << 4), x=self.x)["y"]
+        else:
+            # svi.init reads only the batch's shape; batch_size distinct n x n factors are skipped when
+            # they would not fit a GiB
+            sample_batch = torch.empty((self.batch_size, self.out_dim), dtype=self.dtype, device=self.x.device)
+        state = self.svi.init(self.seed, sample_batch)
+        self.state = state
         rng = np.random.default_rng(self.seed)
         self.test_loss_list = []
+        rank, _ = dist_info()
         for i in range(self.num_epochs):
             k_train, k_test = (int(v) for v in rng.integers(0, 2 ** 31 - 1, size=2))
             t_start = time.time()
             _, state = self.epoch_train(k_train, state)
             test_loss = self.eval_test(k_test, state)
             self.test_loss_list += [test_loss]
-            if self._engine().rank == 0:
+            if rank == 0:
                 print("Epoch {}: loss = {} ({:.2f} s.)".format(i, test_loss, time.time() - t_start))
             if np.isnan(test_loss):  # vae.py:245
+                bad = self.engine.failed_factors() if self.engine is not None else 0
+                if rank == 0 and bad:
+                    print("gp_vae_amd: %d Gram matrices were not positive definite up to epoch %d (jitter %g)"
+                          % (bad, i, self.gp.jitter))
                 break
         self.state = state
-        h0, h1 = self.hidden_dims
-        return decoder_list_from_flat(state.params, self.out_dim, h0, h1, self.z_dim)
+        return self.svi.get_params(state)["decoder$params"]

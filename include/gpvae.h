@@ -100,6 +100,17 @@ int gpvae_draw(void *stream, int dtype, int64_t n, int64_t nb, const void *L, in
                const void *E, int64_t lde, const void *E2, int64_t lde2, const void *sigma,
                void *F, int64_t ldf, void *Y, int64_t ldy);
 
+/* ---- a4: one draw per factor (batched factors) ----------------------------------------------------
+ * Replaces Predictive(gp.sample, num_samples=nb) with hyper-parameters left None
+ * (src/model/vae.py:226, src/test/toy_examples.py:88; priors gp.py:171-176): every sample b has its
+ * own K_b, L_b and noise:   F[b][i] = sum_{j<=i} E[b][j] * L_b[i][j];   Y[b] = F[b] + sigma[b]*E2[b].
+ * L: [nb][n][ldl], factor b at L + b*strideL (only the lower triangle is read); E, E2, F, Y: [nb, ld];
+ * sigma: device array [nb].  E2 NULL => Y = F; F or Y may be NULL.  n*sizeof(T) <= 64 KB.
+ * Bound: HBM (every factor is read once: nb*n^2/2*sizeof(T) bytes).                                */
+int gpvae_draw_batched(void *stream, int dtype, int64_t n, int64_t nb, const void *L, int64_t ldl,
+                       int64_t strideL, const void *E, int64_t lde, const void *E2, int64_t lde2,
+                       const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy);
+
 /* ---- f3: counter-based standard normals (Philox4x32-10 + Box-Muller) -------------------------------
  * Stands in for jax.random.normal (threefry; not reproducible without JAX) in
  * throughput runs; element i depends only on (seed, stream_id, i).  The integers are exact
@@ -167,6 +178,17 @@ int64_t gpvae_vae_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h
 int gpvae_vae_elbo(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,
                    const void *params, const void *Y, int64_t ldy, const void *eps_z,
                    double obs_sigma, void *loss, void *grads, void *work);
+
+/* ---- a5: encoder alone ----------------------------------------------------------------------------
+ * Replaces the apply function of vae_encoder() (src/model/vae.py:72-85) and the guide's sample
+ * z ~ Normal(z_loc, z_std) (vae.py:134-135): mu = enc_mu(Y), sd = exp(enc_logsd(Y)) — the stax.Exp
+ * head returns the standard deviation — and, when eps_z and Z are given, Z = mu + sd * eps_z.
+ * enc_params: the encoder head of the flat layout above (W1 b1 W2 b2 Wmu bmu Wsd bsd; a pointer to
+ * the full flat vector serves).  Y: [B, ldy]; eps_z, mu, sd, Z: [B, z] contiguous.                 */
+int64_t gpvae_encoder_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1, int z);
+int gpvae_encoder_fwd(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,
+                      const void *enc_params, const void *Y, int64_t ldy, const void *eps_z,
+                      void *mu, void *sd, void *Z, void *work);
 
 /* ---- a7: Adam -----------------------------------------------------------------------------------
  * Replaces numpyro.optim.Adam(lr) inside svi.update (vae.py:165,212): b1, b2, eps as given;

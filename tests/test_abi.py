@@ -17,10 +17,22 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(gpvae_[a-z0-9_]+)\s*\(", src)))
 
 
+def exported_symbols():
+    """Dynamic symbols `gpvae_*` of the built library (nm -D; defined text symbols only)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    return sorted(set(re.findall(r"\bT (gpvae_[a-z0-9_]+)$", out, flags=re.M)))
+
+
+def test_exported_symbols_equal_declared_symbols():
+    """No undeclared export (developer probes live behind `make DEV=1`) and nothing declared is missing."""
+    assert exported_symbols() == header_symbols()
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = header_symbols()
-    assert len(names) == 22
+    assert len(names) == 25
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
@@ -55,6 +67,11 @@ def test_argument_validation_without_a_gpu():
     assert lib.gpvae_trsm(null, 0, 2, 8, 4, null, 8, null, 8) == -3   # trans not 0/1
     assert lib.gpvae_trsm(null, 0, 1, 8, 4, null, 8, null, 8) == -6   # L is NULL
     assert lib.gpvae_trsm(null, 0, 1, 0, 4, null, 0, null, 0) == 0    # empty problem
+    assert lib.gpvae_draw_batched(null, 0, 8, 4, null, 8, 64, null, 8, null, 0, null, null, 0, null, 0) == -5  # L NULL
+    assert lib.gpvae_draw_batched(null, 0, 1 << 20, 4, null, 8, 64, null, 8, null, 0, null, null, 0, null, 0) == -3
+    assert lib.gpvae_draw_batched(null, 0, 0, 4, null, 0, 0, null, 0, null, 0, null, null, 0, null, 0) == 0
+    assert lib.gpvae_encoder_fwd(null, 0, 4, 8, 2, 2, 2, null, null, 8, null, null, null, null, null) == -8
+    assert lib.gpvae_encoder_fwd(null, 0, 0, 8, 2, 2, 2, null, null, 8, null, null, null, null, null) == 0
 
 
 def test_size_queries():

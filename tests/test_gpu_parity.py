@@ -5,7 +5,9 @@ Tolerances (BASELINE.json north_star): 1e-5 relative in float64 (we assert 1e-9 
 the arithmetic allows), 1e-3 relative in float32 with the scripts' default jitters.  For float32
 Cholesky FACTORS the attainable forward error is cond(K)*eps, whichever algorithm is used
 (SURVEY.md §6), so the assertion is  err <= max(1e-3, 3 * err of LAPACK's own float32 factor)
-plus a backward-error bound ||L L^T - K|| / ||K|| <= 2e-6.
+plus a backward-error bound ||L L^T - K|| / ||K|| <= 2e-6.  The same yard-stick holds for every
+float32 quantity that goes through a solve (kriging variances, batched kriging, MVN gradients):
+err <= max(1e-3, 3 * error of the ORACLE run in float32 on the same inputs) — `f32_bar` below.
 """
 import numpy as np
 import pytest
@@ -28,6 +30,12 @@ def rel(a, b):
 
 def dev(a, tdt):
     return torch.tensor(np.asarray(a), dtype=tdt, device=DEV)
+
+
+def f32_bar(err_oracle_f32):
+    """The float32 bar: 1e-3 (north_star), or 3x what the oracle's own arithmetic loses in float32 on
+    the same inputs when conditioning puts even LAPACK-on-CPU above 1e-3."""
+    return max(1e-3, 3.0 * float(err_oracle_f32))
 
 
 def grid2(g):
@@ -342,7 +350,13 @@ def test_kriging(ops, golden, ndt, tdt, tol):
     mk = np.ones(20, bool)
     mk[o2] = False
     m2, _, v2, _ = ops.krig_predict(dev(x2[o2], tdt), dev(x2[mk], tdt), dev(y2[o2], tdt), 1.0, 0.2, 0.05)
-    assert rel(m2, g["krigsq_mean"]) < t and rel(v2, g["krigsq_var"]) < (1e-7 if ndt == np.float64 else 5e-2)
+    if ndt == np.float64:
+        assert rel(m2, g["krigsq_mean"]) < t and rel(v2, g["krigsq_var"]) < 1e-7
+    else:  # the variance is a difference of two O(var) numbers: judged against the oracle in float32
+        f = np.float32
+        m32, _, v32 = orc.gp_prediction(x2.astype(f), y2.astype(f), o2, f(1.0), f(0.2), f(0.05))
+        assert rel(m2, g["krigsq_mean"]) < f32_bar(rel(m32, g["krigsq_mean"]))
+        assert rel(v2, g["krigsq_var"]) < f32_bar(rel(v32, g["krigsq_var"])), (rel(v2, g["krigsq_var"]), rel(v32, g["krigsq_var"]))
     # 2-D, several panels, against the literal inverse-based oracle
     rng = np.random.default_rng(4)
     xg = grid2(30)
@@ -418,9 +432,14 @@ def test_kriging_batched(ops, ndt, tdt, tol):
         assert info[2] > 0 and (np.delete(info, 2) == 0).all()
         assert np.isnan(m[2].cpu().numpy()).all()
         for s in (0, 1, 3, 4):
-            mo, po, vo = orc.gp_prediction(x.astype(ndt), y.astype(ndt), obs, ndt(var[s]), ndt(ls[s]), ndt(sig[s]), xi[s].astype(ndt))
-            t = tol * 50 if ndt == np.float32 else 1e-7
-            assert rel(m[s], mo) < t and rel(p[s], po) < t, (d, s)
+            mo, po, vo = orc.gp_prediction(x, y, obs, var[s], ls[s], sig[s], xi[s])  # float64 truth
+            if ndt == np.float64:
+                assert rel(m[s], mo) < 1e-7 and rel(p[s], po) < 1e-7, (d, s)
+            else:
+                f = np.float32
+                m32, p32, _ = orc.gp_prediction(x.astype(f), y.astype(f), obs, f(var[s]), f(ls[s]), f(sig[s]), xi[s].astype(f))
+                assert rel(m[s], mo) < f32_bar(rel(m32, mo)), (d, s, rel(m[s], mo), rel(m32, mo))
+                assert rel(p[s], po) < f32_bar(rel(p32, po)), (d, s, rel(p[s], po), rel(p32, po))
 
 
 # ---- a10 / f1 ---------------------------------------------------------------------------------------------------
@@ -440,15 +459,24 @@ def test_mvn_logp_and_gradient(ops, ndt, tdt, tol):
         lp, gf, gv, gl, info = ops.mvn_logp(dev(x.astype(ndt), tdt), dev(F, tdt), var_bad, ls, jit)
         info = info.cpu().numpy()
         assert info[2] > 0 and np.isnan(lp[2].item()) and np.isnan(gv[2].item())
+        # fp32: cond(K) ~ 1e5 at these sizes; d/dvar and d/dls are differences of two O(n) terms
+        # (alpha^T dK alpha and tr(K^-1 dK)).  The bar is 1e-3 unless the oracle's own arithmetic run
+        # in float32 on these inputs loses more (worst chain of the batch on both sides).
+        e_gpu, e_o32 = np.zeros(3), np.zeros(3)
         for s in (0, 1, 3):
             lo, gfo, gvo, glo = orc.mvn_logp_grads(x, F[s], var[s], ls[s], jit)
-            # fp32: cond(K) ~ 1e5 at these sizes; d/dvar and d/dls are differences of two O(n) terms
-            # (alpha^T dK alpha and tr(K^-1 dK)), each good to ~1e-4 relative, so the bound scales
-            # with n; the value itself is good to 3e-5
-            t = 1e-7 if ndt == np.float64 else max(1e-2, 1e-4 * n)
             assert abs(lp[s].item() - lo) < (1e-7 if ndt == np.float64 else 1e-3) * abs(lo), (n, s)
-            assert rel(gf[s], gfo) < t, (n, s)
-            assert abs(gv[s].item() - gvo) < t * max(1.0, abs(gvo)) and abs(gl[s].item() - glo) < t * max(1.0, abs(glo)), (n, s)
+            errs = (rel(gf[s], gfo), abs(gv[s].item() - gvo) / max(1.0, abs(gvo)), abs(gl[s].item() - glo) / max(1.0, abs(glo)))
+            if ndt == np.float64:
+                assert max(errs) < 1e-7, (n, s, errs)
+                continue
+            f = np.float32
+            _, gf3, gv3, gl3 = orc.mvn_logp_grads(x.astype(f), F[s].astype(f), f(var[s]), f(ls[s]), f(jit))
+            o32 = (rel(gf3, gfo), abs(gv3 - gvo) / max(1.0, abs(gvo)), abs(gl3 - glo) / max(1.0, abs(glo)))
+            e_gpu, e_o32 = np.maximum(e_gpu, errs), np.maximum(e_o32, o32)
+        if ndt == np.float32:
+            for q in range(3):
+                assert e_gpu[q] < f32_bar(e_o32[q]), (n, q, e_gpu, e_o32)
 
 
 def test_gp_regression_potential_gradient(ops, golden):

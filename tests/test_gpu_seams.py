@@ -1,0 +1,302 @@
+"""GPU tests of the reference's call seams and of the entry points added for them:
+Predictive(gp.sample) with per-sample hyper-parameters (batched factors + gpvae_draw_batched),
+vae_encoder's apply (gpvae_encoder_fwd), SVI.init/update/evaluate/get_params driven by an EXTERNAL
+batch, the literal training loop vs the pipelined StepEngine, regression / gp_regression handed to the
+MCMC drivers, chain sharding.  Everything goes ctypes -> C ABI; the checker is the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a, tdt):
+    return torch.tensor(np.asarray(a), dtype=tdt, device=DEV)
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", [(np.float64, torch.float64, 1e-12), (np.float32, torch.float32, 1e-5)])
+def test_draw_batched_against_oracle(ndt, tdt, tol):
+    """gpvae_draw_batched: one draw per factor, ragged n, padded leading dimensions, junk above the
+    diagonal, with and without the noise term."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(3)
+    for n, nb in ((1, 1), (63, 7), (64, 3), (300, 100), (517, 9)):
+        L = np.tril(rng.standard_normal((nb, n, n)))
+        E, E2 = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
+        sig = rng.uniform(0.01, 0.3, nb)
+        buf = torch.zeros((nb, n, n + 3), dtype=tdt, device=DEV)
+        buf[:, :, :n] = dev(L, tdt) + torch.triu(torch.full((n, n), 9.0, dtype=tdt, device=DEV), 1)
+        F, Y = ops.draw_batched(buf[:, :, :n], dev(E, tdt), dev(E2, tdt), dev(sig, tdt), want_f=True)
+        Fo = np.einsum("bij,bj->bi", L, E)
+        assert rel(F, Fo) < tol and rel(Y, Fo + sig[:, None] * E2) < tol, (n, nb)
+        assert rel(ops.draw_batched(buf[:, :, :n], dev(E, tdt)), Fo) < tol
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", [(np.float64, torch.float64, 1e-9), (np.float32, torch.float32, 1e-3)])
+def test_predictive_per_sample_hyperparameters_c1(ndt, tdt, tol):
+    """Predictive(gp.sample, B)(key, x=x) with ls/var/sigma left None (vae.py:226, toy_examples.py:88):
+    B = 100 distinct K / L at n = 300 (C1) — f, y and the length / var / noise sites vs the oracle."""
+    from gp_vae_amd import ops
+    from gp_vae_amd.gp import GP, Predictive, draw_hyper, exp_kernel2
+    n, B, jit, seed = 300, 100, 1e-4, 11
+    x = np.arange(0, 1, 1 / n)
+    gp = GP(kernel=exp_kernel2, jitter=jit, d=1)
+    out = Predictive(gp.sample, num_samples=B)(seed, x=torch.tensor(x, dtype=tdt))
+    ls, var, sig = draw_hyper(np.random.default_rng(seed), B)  # the documented host stream of the sites
+    assert rel(out["length"], ls) < 1e-6 and rel(out["var"], var) < 1e-6 and rel(out["noise"], sig) < 1e-6
+    assert int(gp.last_info.abs().sum().item()) == 0
+    E = ops.randn((B, n), tdt, DEV, seed=seed, stream_id=1).cpu().numpy().astype(np.float64)
+    E2 = ops.randn((B, n), tdt, DEV, seed=seed, stream_id=2).cpu().numpy().astype(np.float64)
+    worst_f = worst_o32 = 0.0
+    for b in range(B):
+        hy = [ndt(v) for v in (var[b], ls[b], sig[b])]  # the device sees the hyper-parameters in its dtype
+        L = orc.cholesky_lower(orc.exp_kernel2(x, x, float(hy[0]), float(hy[1]), jit))
+        Fo, Yo = orc.gp_draw(L, E[b:b + 1], float(hy[2]), E2[b:b + 1])
+        worst_f = max(worst_f, rel(out["f"][b], Fo[0]), rel(out["y"][b], Yo[0]))
+        if ndt == np.float32:  # yard-stick: LAPACK's own float32 factor of the same matrix
+            K32 = orc.exp_kernel2(x.astype(ndt), x.astype(ndt), hy[0], hy[1], ndt(jit)).astype(ndt)
+            F32 = E[b].astype(ndt) @ np.linalg.cholesky(K32).T
+            worst_o32 = max(worst_o32, rel(F32, Fo[0]))
+    assert worst_f < max(tol, 3 * worst_o32), (worst_f, worst_o32)
+    # fixed ls, sampled var / noise: only the sampled sites are returned (gp.py:171-176)
+    out2 = Predictive(gp.sample, num_samples=5)(3, x=torch.tensor(x, dtype=tdt), ls=0.2)
+    assert "length" not in out2 and out2["var"].shape == (5,) and out2["noise"].shape == (5,)
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", [(np.float64, torch.float64, 1e-11), (np.float32, torch.float32, 1e-4)])
+def test_encoder_apply_and_guide(ndt, tdt, tol):
+    from gp_vae_amd import ops
+    from gp_vae_amd.gp import GP
+    from gp_vae_amd.vae import VAE, encoder_list_from_flat
+    rng = np.random.default_rng(4)
+    for B, n, h0, h1, z in ((100, 300, 35, 30, 10), (37, 625, 50, 30, 15), (5, 19, 3, 2, 1), (64, 256, 512, 256, 64)):
+        p = {k: 8 * v for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+        Y, ez = rng.standard_normal((B, n)), rng.standard_normal((B, z))
+        mu_o, sd_o = orc.encoder(p, Y)
+        flat = dev(orc.flatten(p), tdt)
+        mu, sd, zz = ops.encoder_fwd(flat, dev(Y, tdt), (h0, h1, z), dev(ez, tdt))
+        assert rel(mu, mu_o) < tol and rel(sd, sd_o) < tol and rel(zz, mu_o + sd_o * ez) < tol, (B, n)
+        vae = VAE(GP(), [h0, h1], z, n, B, 1e-3, 1, 1, 1, np.arange(n) / n, dtype=tdt)
+        init, apply = vae.vae_encoder()
+        (shape_mu, shape_sd), plist = init(3, (B, n))
+        assert shape_mu == (z,) and plist[0][0].shape == (n, h0) and plist[5][1][0][0].shape == (h1, z)
+        m2, s2 = apply(encoder_list_from_flat(flat, n, h0, h1, z), dev(Y, tdt))
+        assert torch.equal(m2, mu) and torch.equal(s2, sd)
+        assert apply(encoder_list_from_flat(flat, n, h0, h1, z), dev(Y[0], tdt))[0].shape == (z,)
+        # vae_guide: z ~ Normal(z_loc, z_std) with the key's normals; vae_model returns the observed batch
+        zg = vae.vae_guide(dev(Y, tdt), params=flat, rng_key=9)
+        eg = ops.randn((B, z), tdt, DEV, seed=9, stream_id=3).cpu().numpy().astype(np.float64)
+        assert rel(zg, mu_o + sd_o * eg) < tol
+        obs = vae.vae_model(dev(Y, tdt), params=flat, z=zg)
+        assert torch.equal(obs, dev(Y, tdt)) and rel(vae.last_f, orc.decoder(p, zg.cpu().numpy().astype(np.float64))) < tol
+
+
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-8), (torch.float32, np.float32, 2e-3)])
+def test_svi_seam_c1_epoch_matches_oracle(tdt, ndt, tol):
+    """A C1 epoch (n=300, B=100, 35/30/10, jitter 1e-4) driven as the reference drives it —
+    hyper draw -> Predictive(gp.sample) -> svi.update(state, batch['y']) — NOT through StepEngine;
+    losses and parameters vs oracle.train_step on the same inputs; evaluate / get_params."""
+    from gp_vae_amd import ops
+    from gp_vae_amd.gp import GP, PhiloxKey, Predictive, draw_hyper, exp_kernel2
+    from gp_vae_amd.vae import SVI, VAE, Adam, Trace_ELBO
+    n, B, dims, lr, jit = 300, 100, (35, 30, 10), 1e-3, 1e-4
+    x = np.arange(0, 1, 1 / n)
+    gp = GP(kernel=exp_kernel2, jitter=jit, d=1)
+    vae = VAE(gp, list(dims[:2]), dims[2], n, B, lr, 1, 6, 2, x, seed=1, dtype=tdt)
+    svi = SVI(vae.vae_model, vae.vae_guide, Adam(lr), Trace_ELBO())
+    gp_predictive = Predictive(gp.sample, num_samples=B)
+    state = svi.init(5, gp_predictive(rng_key=1, x=vae.x)["y"])
+    assert state.t == 0 and state.params.numel() == ops.vae_param_count(n, *dims)
+    p = orc.unflatten(state.params.cpu().numpy().astype(np.float64), n, *dims)
+    p = {k: 5 * v for k, v in p.items()}  # larger weights: gradients well above rounding
+    state.params.mul_(5)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(a) for k, a in p.items()}
+    rng = np.random.default_rng(0)
+    for t in range(1, 7):
+        ls, var, sig = (float(ndt(a)) for a in draw_hyper(rng))
+        key = PhiloxKey(77, t << 4)
+        batch = gp_predictive(key, vae.x, ls=ls, var=var, sigma=sig)
+        state, loss = svi.update(state, batch["y"], rng_key=key)
+        E, E2, ez = (ops.randn(s, tdt, DEV, seed=77, stream_id=(t << 4) | i).cpu().numpy().astype(np.float64)
+                     for i, s in ((1, (B, n)), (2, (B, n)), (3, (B, dims[2]))))
+        want, p, m, v = orc.train_step(p, m, v, t, x, (ls, var, sig), E, E2, ez, lr, jit)
+        assert abs(loss.item() - want) < tol * abs(want), t
+    assert state.t == 6 and rel(state.params, orc.flatten(p)) < tol
+    # evaluate leaves the state alone and equals the oracle's loss on an external batch
+    Yext, key = np.random.default_rng(1).standard_normal((B, n)), PhiloxKey(5, 0x70)
+    before = state.params.clone()
+    le = svi.evaluate(state, dev(Yext, tdt), rng_key=key).item()
+    ez = ops.randn((B, dims[2]), tdt, DEV, seed=5, stream_id=0x73).cpu().numpy().astype(np.float64)
+    pe = orc.unflatten(state.params.cpu().numpy().astype(np.float64), n, *dims)
+    assert abs(le - orc.elbo_loss(pe, Yext, ez)) < max(tol, 1e-4) * abs(le) and torch.equal(before, state.params)
+    # the default key stream advances with the step count: two updates on one batch use different normals
+    l1 = svi.evaluate(state, dev(Yext, tdt)).item()
+    state.t += 1
+    assert svi.evaluate(state, dev(Yext, tdt)).item() != l1
+    state.t -= 1
+    got = svi.get_params(state)
+    assert [tuple(a.shape) for a in (got["decoder$params"][0][0], got["decoder$params"][4][0])] == [(10, 30), (35, 300)]
+    assert got["encoder$params"][0][0].shape == (300, 35)
+    # only this model / guide / optimiser / loss
+    with pytest.raises(NotImplementedError):
+        SVI(lambda b: b, vae.vae_guide, Adam(lr), Trace_ELBO())
+    with pytest.raises(NotImplementedError):
+        SVI(vae.vae_model, VAE(gp, [35, 30], 10, n, B, lr, 1, 1, 1, x).vae_guide, Adam(lr), Trace_ELBO())
+
+
+def test_literal_loop_equals_pipelined_engine():
+    """VAE(pipelined=False) — draw hyper -> gp_predictive -> svi.update, one launch sequence per step —
+    and the pipelined StepEngine (factor stream, batched factors) are the same arithmetic on the same
+    keys: epoch_train and eval_test agree (f64: to rounding of the atomics' order)."""
+    from gp_vae_amd.gp import GP, exp_kernel2
+    from gp_vae_amd.vae import VAE
+    n = 96
+    x = np.arange(0, 1, 1 / n)
+    res = []
+    for pipelined in (True, False):
+        gp = GP(kernel=exp_kernel2, jitter=1e-3, d=1)
+        vae = VAE(gp, [12, 9], 4, n, 40, 1e-3, 1, 7, 3, x, seed=3, dtype=torch.float64, pipelined=pipelined)
+        st = vae.svi_init()
+        st.params.mul_(5)
+        loss, st = vae.epoch_train(123, st)
+        res.append((loss.item(), st.params.clone(), vae.eval_test(9, st), st.t))
+    assert res[0][3] == res[1][3] == 7
+    assert abs(res[0][0] - res[1][0]) < 1e-10 * abs(res[0][0])
+    assert rel(res[0][1], res[1][1].cpu().numpy()) < 1e-10
+    assert abs(res[0][2] - res[1][2]) < 1e-10 * abs(res[0][2])
+
+
+def test_step_engine_2d_points_any_strides_and_kernel_guard():
+    """a transposed (column-major) [n,2] x — the scripts' array([u,v]).transpose idiom
+    (2d_examples.py:564) — must train on the same locations as its contiguous copy, and match the
+    oracle; a GP with another kernel must not silently train on the squared-exponential one."""
+    from gp_vae_amd import ops, parallel
+    from gp_vae_amd.gp import GP, draw_hyper
+    from gp_vae_amd.vae import StepEngine, SVIState, VAE
+    g = np.arange(0, 1, 1 / 12)
+    u, v = np.meshgrid(g, g)
+    xt = torch.tensor(np.array([u.flatten(), v.flatten()]), dtype=torch.float64, device=DEV).transpose(1, 0)
+    assert not xt.is_contiguous() and xt.shape == (144, 2)
+    xc = xt.contiguous()
+    n, B, dims = 144, 32, (10, 8, 3)
+    out = []
+    for x in (xt, xc):
+        eng = StepEngine(x, 1e-3, dims, B, 1e-3, dtype=torch.float64, seed=2, group=2)
+        p = orc.init_params(np.random.default_rng(0), n, *dims, np.float64)
+        st = SVIState(torch.tensor(orc.flatten(p), dtype=torch.float64, device=DEV) * 5)
+        out.append((eng.run([(4, 0), (4, 1)], st, train=True).item(), st.params.clone()))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-12) and rel(out[0][1], out[1][1].cpu().numpy()) < 1e-12
+    p = {k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}
+    m = {k: np.zeros_like(a) for k, a in p.items()}
+    vv = {k: np.zeros_like(a) for k, a in p.items()}
+    want = 0.0
+    for t, key in enumerate([(4, 0), (4, 1)], 1):
+        E, E2, ez = (ops.randn(s, torch.float64, DEV, seed=2, stream_id=parallel.philox_stream_id(0, key, i)).cpu().numpy()
+                     for i, s in ((1, (B, n)), (2, (B, n)), (3, (B, dims[2]))))
+        loss, p, m, vv = orc.train_step(p, m, vv, t, xc.cpu().numpy(), draw_hyper(parallel.step_rng(2, 0, key)), E, E2, ez, 1e-3, 1e-3)
+        want += loss
+    assert abs(out[0][0] - want) < 1e-8 * abs(want) and rel(out[0][1], orc.flatten(p)) < 1e-8
+    with pytest.raises(NotImplementedError):
+        StepEngine(xc, 1e-3, dims, B, 1e-3, kernel=lambda *a, **k: None)
+    other = GP(kernel=lambda x, z, var, ls, jitter=1e-5: ops.gram_se(x, z, var, ls, jitter), jitter=1e-3, d=2)
+    vae = VAE(other, [10, 8], 3, n, B, 1e-3, 1, 2, 1, xc, dtype=torch.float64)
+    with pytest.raises(NotImplementedError):
+        vae.epoch_train(1, vae.svi_init())
+    # ... but the literal loop honours an injected kernel (here: the same arithmetic through a wrapper)
+    vae2 = VAE(other, [10, 8], 3, n, B, 1e-3, 1, 2, 1, xc, seed=2, dtype=torch.float64, pipelined=False)
+    loss, st = vae2.epoch_train(1, vae2.svi_init())
+    assert np.isfinite(loss.item()) and st.t == 2 and eng.failed_factors() == 0
+
+
+def test_regression_seams_and_chain_sharding(monkeypatch):
+    """regression / gp_regression called as the reference calls them: with data they return what the
+    MCMC driver is given; through Predictive they return prior / posterior predictive draws;
+    gp_run_mcmc(rng_key, x, y, model) keeps the reference's argument list; chains sharded over two
+    (emulated) ranks reproduce the single-process chains exactly."""
+    from gp_vae_amd import parallel
+    from gp_vae_amd.gp import Predictive, exp_kernel2
+    from gp_vae_amd.inference import GPInference, Potential, VAEInference
+    rng = np.random.default_rng(2)
+    n = 40
+    x = np.arange(n) / n
+    obs = np.sort(rng.permutation(n)[:12])
+    y = np.full(n, np.nan); y[obs] = np.sin(6 * x[obs]) + 0.05 * rng.standard_normal(12)
+    args = {"num_warmup": 30, "num_samples": 20, "num_chains": 4, "thinning": 1}
+    inf = GPInference(exp_kernel2, 1, x, y, obs, args, seed=5, dtype=torch.float64)
+    pot = inf.gp_regression(inf.x[inf.obs_idx], inf.y[inf.obs_idx])
+    assert isinstance(pot, Potential) and pot.init.shape == (15,)
+    q = pot.init[None, :].repeat(3, 1) + 0.01 * torch.randn(3, 15, dtype=torch.float64, device=DEV)
+    U, dU = pot(q)
+    for c in range(3):
+        qq = q[c].cpu().numpy()
+        assert abs(U[c].item() - orc.gp_regression_potential(x[obs], y[obs], qq[:12], qq[12], qq[13], qq[14])) < 1e-9 * abs(U[c].item())
+    # full-grid model (inference.py:359-397): latent f on all n points, likelihood on the observed ones
+    potf = inf.regression(y=inf.y, obs_idx=inf.obs_idx)
+    qf = potf.init[None, :] + 0.01 * torch.randn(2, n + 3, dtype=torch.float64, device=DEV)
+    Uf, dUf = potf(qf)
+    h = 1e-6
+    for j in (3, int(obs[2]), n, n + 1, n + 2):  # an unobserved f, an observed f, the three hyper-parameters
+        e = torch.zeros_like(qf); e[:, j] = h
+        fd = (potf(qf + e)[0] - potf(qf - e)[0]) / (2 * h)
+        assert torch.allclose(dUf[:, j], fd, rtol=2e-4, atol=2e-4), j
+    prior = Predictive(inf.regression, num_samples=50)(3)["y_pred"]
+    assert prior.shape == (50, n) and torch.isfinite(prior).all()
+    post = inf.gp_run_mcmc(7, inf.x[inf.obs_idx], inf.y[inf.obs_idx], model=inf.gp_regression)
+    assert post["f"].shape == (80, 12) and post["kernel_var"].shape == (80,)
+    pp = Predictive(inf.gp_regression, post)(4, inf.x[inf.obs_idx])["y_pred"]
+    assert pp.shape == (80, 12)
+    # chain sharding: rank r of 2 runs chains r, r+2 and gets the very samples of the one-process run
+    whole = post["f"].reshape(4, 20, 12)
+    for r in range(2):
+        monkeypatch.setattr(parallel, "dist_info", lambda r=r: (r, 2))
+        part = inf.gp_run_mcmc(7, inf.x[inf.obs_idx], inf.y[inf.obs_idx], model=inf.gp_regression)["f"]
+        assert inf.chain_ids == [r, r + 2] and part.shape == (40, 12)
+        assert torch.allclose(part.reshape(2, 20, 12), whole[[r, r + 2]], rtol=1e-9, atol=1e-12)
+    monkeypatch.undo()
+    # VAE-prior model
+    nz, h1, h0 = 6, 9, 12
+    p = orc.init_params(rng, n, h0, h1, nz, np.float64)
+    dec = [(50 * p["V1"], p["c1"]), (), (50 * p["V2"], p["c2"]), (), (50 * p["V3"], p["c3"])]
+    vinf = VAEInference(None, dec, nz, 1, x, y, obs, args, seed=6, dtype=torch.float64)
+    vp = vinf.regression(y=vinf.y, obs_idx=vinf.obs_idx)
+    Z, u = rng.standard_normal((5, nz)), np.log(0.1) + 0.1 * rng.standard_normal(5)
+    Uv, _ = vp(torch.tensor(np.concatenate([Z, u[:, None]], 1), device=DEV))
+    pscaled = dict(p, V1=50 * p["V1"], V2=50 * p["V2"], V3=50 * p["V3"])
+    assert rel(Uv, orc.vae_potential(pscaled, Z, u, y, obs)) < 1e-10
+    pr = Predictive(vinf.regression, num_samples=30)(1)
+    assert pr["y_pred"].shape == (30, n) and pr["z"].shape == (30, nz) and (pr["noise"] >= 0).all()
+    smp = vinf.run_mcmc(3)
+    assert smp["z"].shape == (80, nz) and smp["f"].shape == (80, n) and smp["noise"].shape == (80,)
+
+
+def test_decoder_reference_shapes_and_nan_weights():
+    """Decoder forward / VJP at the shapes and weight spread of the reference's six decoder files
+    (src/test/decoders/*: (10,30),(30,35),(35,300) and (15,30),(30,50),(50,625), std 0.15-0.2; SURVEY.md
+    §4).  The files themselves are refused by the safe loaders (tests/golden/make_decoder_fixtures.py), so
+    the weights are synthetic.  One of the files is all-NaN (a diverged run): NaN weights must give NaN
+    outputs, not a fault."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(70)
+    for z, h1, h0, n in ((10, 30, 35, 300), (15, 30, 50, 625)):
+        shapes = [(z, h1), (h1,), (h1, h0), (h0,), (h0, n), (n,)]
+        w = [rng.normal(0, 0.18, s) for s in shapes]
+        p = dict(zip(("V1", "c1", "V2", "c2", "V3", "c3"), w))
+        Z = rng.standard_normal((16, z)); Z[0] = 0.0
+        dF = rng.standard_normal((16, n))
+        for tdt, tol in ((torch.float64, 1e-12), (torch.float32, 1e-5)):
+            flat = dev(np.concatenate([a.reshape(-1) for a in w]), tdt)
+            assert rel(ops.decoder_fwd(flat, dev(Z, tdt), n, h0, h1), orc.decoder(p, Z)) < tol
+            assert rel(ops.decoder_vjp(flat, dev(Z, tdt), dev(dF, tdt), h0, h1), orc.decoder_vjp(p, Z, dF)) < tol
+        bad = torch.full_like(flat, float("nan"))
+        assert torch.isnan(ops.decoder_fwd(bad, dev(Z, torch.float32), n, h0, h1)).all()

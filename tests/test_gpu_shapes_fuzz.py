@@ -149,9 +149,12 @@ def test_kriging_random_shapes(ops, ndt, tdt):
         assert info.item() == 0, tag
         if ndt == np.float64:
             assert rel(md, mo) < 1e-7 and np.abs(vd.cpu().numpy() - vo).max() < 1e-8 and rel(sd, so) < 1e-6, tag
-        else:  # f32: the observation noise sigma >= 0.05 bounds cond(k_xx + sigma I) by about n_obs * 40
-            assert rel(md, mo) < 3e-3, tag + (rel(md, mo),)
-            assert np.abs(vd.cpu().numpy() - vo).max() < 3e-3 * var, tag
+        else:  # f32: 1e-3 (north_star), or 3x what the oracle's arithmetic loses in float32 on these inputs
+            f = np.float32
+            m32, _, v32 = orc.gp_prediction(x.astype(f), y.astype(f), obs, f(var), f(ls), f(sigma), xi.astype(f))
+            assert rel(md, mo) < max(1e-3, 3 * rel(m32, mo)), tag + (rel(md, mo), rel(m32, mo))
+            ev, ev32 = np.abs(vd.cpu().numpy() - vo).max() / var, np.abs(v32 - vo).max() / var
+            assert ev < max(1e-3, 3 * ev32), tag + (ev, ev32)
 
 
 @pytest.mark.parametrize("ndt,tdt", DTYPES)

@@ -120,3 +120,41 @@ def test_hmc_recovers_a_gaussian_target():
     a, _ = hmc(pot, torch.zeros((2, 3), dtype=torch.float64), 20, 40, thinning=4, seed=9)
     b, _ = hmc(pot, torch.zeros((2, 3), dtype=torch.float64), 20, 40, thinning=4, seed=9)
     assert a.shape == (10, 2, 3) and torch.equal(a, b)
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher must start 2 ranks itself (the flag was
+    parsed and ignored).  --dry-run: gloo, stand-in gradient, no GPU work — the launcher, rendezvous and
+    the path's one collective are what is exercised."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["dry_run"] and out["allreduce_sum_checked"] == 3.0
+    one = _run_bench(["--gpus", "1", "--dry-run"])
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """Under a launcher (WORLD_SIZE set) a different --gpus is an error, never a mislabelled number."""
+    r = _run_bench(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_chains_shard_without_overlap():
+    from gp_vae_amd.parallel import shard
+    for world in (1, 2, 8):
+        got = sorted(c for r in range(world) for c in shard(1024, r, world))
+        assert got == list(range(1024))
