@@ -7,6 +7,9 @@
 //   logp  = -1/2 |L^-1 f|^2 - sum_i log L_ii - n/2 log 2 pi                    K = L L^T
 //   dlogp/df   = -alpha,                      alpha = K^-1 f
 //   dlogp/dvar = 1/(2 var)   sum_ij G_ij K0_ij,       G = alpha alpha^T - K^-1,  K0 = K - jitter I
+//              = 1/(2 var) [ (|w|^2 - n) - jitter (|alpha|^2 - |U|_F^2) ],   w = L^-1 f, U = L^-T
+//     (sum_ij G_ij K_ij = f^T alpha - tr(I); the form with K0 entries loses digits in the float32
+//      cancellation between alpha_i alpha_j K0_ij and K^-1_ij K0_ij, the one with norms does not)
 //   dlogp/dls  = 1/(2 ls^3)  sum_ij G_ij K0_ij r_ij^2,       r_ij = |x_i - x_j|
 // The reference gets these by reverse-mode through jnp.linalg.cholesky; here they are closed form.
 //
@@ -51,21 +54,28 @@ __global__ void mvn_fill_kernel(int64_t n, T *X, int64_t ldx, int64_t strideX, c
   }
 }
 
-// one wave per row i: alpha_i = U[i,:] . w ; logp -= log L_ii + w_i^2 / 2.  grid (ceil(n/4), batch)
+// one wave per row i: alpha_i = U[i,:] . w ; logp -= log L_ii + w_i^2 / 2 ; the row's share of the
+// d/dvar sum: (w_i^2 - 1) - jitter (alpha_i^2 - |U[i,:]|^2).  grid (ceil(n/4), batch)
 template <typename T>
 __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, int64_t lda,
                                                          int64_t strideA, const T *X, int64_t ldx,
                                                          int64_t strideX, const int32_t *info,
-                                                         T *alpha, T *grad_f, T *logp) {
+                                                         T *alpha, T *grad_f, T *logp, T jitter,
+                                                         T *acc2) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t b = blockIdx.y;
   if (i >= n) return;
   const T *U = X + b * strideX;
   const T *w = U + n * ldx;
-  T dot = T(0);
-  for (int64_t k = i + lane; k < n; k += 64) dot += U[i * ldx + k] * w[k];  // U is upper triangular
+  T dot = T(0), usq = T(0);
+  for (int64_t k = i + lane; k < n; k += 64) {  // U is upper triangular
+    const T u = U[i * ldx + k];
+    dot += u * w[k];
+    usq += u * u;
+  }
   dot = wave_sum<T>(dot);
+  usq = wave_sum<T>(usq);
   if (lane == 0) {
     const bool bad = info[b] != 0;
     const T a = bad ? dnan<T>() : dot;
@@ -73,6 +83,7 @@ __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, 
     if (grad_f) grad_f[b * n + i] = -a;
     const T lii = A[b * strideA + i * lda + i];
     atomicAdd(&logp[b], bad ? dnan<T>() : -(dlog<T>(lii) + T(0.5) * w[i] * w[i]));
+    if (acc2 != nullptr) atomicAdd(&acc2[2 * b], (w[i] * w[i] - T(1)) - jitter * (a * a - usq));
   }
 }
 
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mvn_grad_kernel(
   if (kmin < n) pipe.run(la, lb, lds, kmin, n, wm, wn, lane, tid, acc);
 
   const T var = var_p[b], ls = ls_p[b];
-  T s1 = T(0), s2 = T(0);
+  T s2 = T(0);  // (the d/dvar sum comes from mvn_finish_kernel's norms)
 #pragma unroll
   for (int fn = 0; fn < F; ++fn) {
     const int64_t j = q0 + wn + fn * M::TM + M::col(lane);
@@ -127,21 +138,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mvn_grad_kernel(
         const T q = dsqrt<T>(d2) / ls;  // the Gram kernel's own arithmetic (gp.py:74-77)
         const T k0 = var * dexp<T>(T(-0.5) * (q * q));
         const T g = in ? (alpha[b * n + (in ? i : 0)] * aj - acc[fm][fn][r]) * k0 : T(0);
-        s1 += g;
         s2 += g * d2;
       }
   }
-  s1 = wave_sum<T>(s1);
   s2 = wave_sum<T>(s2);
-  if (lane == 0) {
-    red[wave] = s1;
-    red[4 + wave] = s2;
-  }
+  if (lane == 0) red[wave] = s2;
   __syncthreads();
-  if (tid == 0) {
-    atomicAdd(&acc2[2 * b], red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(&acc2[2 * b + 1], red[4] + red[5] + red[6] + red[7]);
-  }
+  if (tid == 0) atomicAdd(&acc2[2 * b + 1], red[0] + red[1] + red[2] + red[3]);
 }
 
 // grad_var = s1 / (2 var), grad_ls = s2 / (2 ls^3); NaN when the factorisation failed
@@ -175,8 +178,8 @@ static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const
   if (rc) return rc;
   hipLaunchKernelGGL((mvn_finish_kernel<T>), dim3((unsigned)cdiv(n, 4), (unsigned)batch), dim3(256),
                      0, st, n, A, w.lda, w.a_elems, X, w.lda, w.x_elems, info, alpha, (T *)grad_f,
-                     (T *)logp);
-  if (grad_var || grad_ls) {
+                     (T *)logp, (T)jitter, grad_var ? acc2 : (T *)nullptr);
+  if (grad_ls) {
     const dim3 grid((unsigned)cdiv(n, 128), (unsigned)cdiv(n, 128), (unsigned)batch);
     const bool vec = kc_vec_ok<T>(X, w.lda) && (w.x_elems % VecT<T>::N) == 0;
     auto launch = [&](auto dd, auto vv) {
@@ -191,9 +194,10 @@ static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const
       if (vec) launch(std::integral_constant<int, 2>{}, std::true_type{});
       else launch(std::integral_constant<int, 2>{}, std::false_type{});
     }
+  }
+  if (grad_var || grad_ls)
     hipLaunchKernelGGL((mvn_scale_kernel<T>), dim3((unsigned)cdiv(batch, 256)), dim3(256), 0, st, batch,
                        (const T *)var, (const T *)ls, info, acc2, (T *)grad_var, (T *)grad_ls);
-  }
   GPVAE_CHECK_LAUNCH("gpvae_mvn_logp");
   return 0;
 }

@@ -24,6 +24,13 @@ from .parallel import dist_info, shard
 from .vae import decoder_flat_from_list
 
 
+def _index(idx, device):
+    """Index array (list / numpy / tensor on any device) as a long tensor on `device`."""
+    if isinstance(idx, torch.Tensor):
+        return idx.to(device=device, dtype=torch.long)
+    return torch.as_tensor(np.asarray(idx), dtype=torch.long, device=device)
+
+
 class Potential():
     """What NUTS/HMC needs of a NumPyro model conditioned on data: the potential energy in the
     unconstrained space and its gradient for a batch of chains (`__call__(q [C, dim]) -> (U [C],
@@ -47,7 +54,7 @@ class Inference():
         self.d = d
         self.x = _as_device(x, dtype)
         self.y = _as_device(y, dtype)
-        self.obs_idx = torch.as_tensor(np.asarray(obs_idx), dtype=torch.long, device=self.x.device)
+        self.obs_idx = _index(obs_idx, self.x.device)
         self.mcmc_args = mcmc_args
         self.seed = seed
         self.ground_truth = ground_truth
@@ -233,8 +240,7 @@ class GPInference(Inference):
         what Predictive(self.regression, num_samples | posterior_samples)(rng_key) returns."""
         if y is None:
             return self._predictive_draws(self.x, rng_key, num_samples or 1, posterior_samples)
-        idx = self.obs_idx if obs_idx is None else torch.as_tensor(np.asarray(obs_idx), dtype=torch.long,
-                                                                    device=self.x.device)
+        idx = self.obs_idx if obs_idx is None else _index(obs_idx, self.x.device)
         yy = _as_device(y, self.dtype)
         return self._latent_gp_model(self.x, yy[idx], idx)
 
@@ -333,8 +339,7 @@ class VAEInference(Inference):
             f = self.predict(z)
             y_pred = f + noise[:, None] * ops.randn(tuple(f.shape), dt, dev, seed=seed, stream_id=base | 7)
             return {"noise": noise, "z": z, "f": f, "y_pred": y_pred}
-        idx = self.obs_idx if obs_idx is None else torch.as_tensor(np.asarray(obs_idx), dtype=torch.long,
-                                                                    device=dev)
+        idx = self.obs_idx if obs_idx is None else _index(obs_idx, dev)
         y_obs = _as_device(y, dt)[idx]
         q0 = torch.zeros(zd + 1, dtype=dt, device=dev)
         q0[zd] = math.log(0.0674)  # median of HalfNormal(0.1)

@@ -245,11 +245,11 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
     potf = inf.regression(y=inf.y, obs_idx=inf.obs_idx)
     qf = potf.init[None, :] + 0.01 * torch.randn(2, n + 3, dtype=torch.float64, device=DEV)
     Uf, dUf = potf(qf)
-    h = 1e-6
+    h = 1e-5  # cond(K) ~ 1e6 at jitter 1e-5: the differences carry ~1e-4 of rounding noise
     for j in (3, int(obs[2]), n, n + 1, n + 2):  # an unobserved f, an observed f, the three hyper-parameters
         e = torch.zeros_like(qf); e[:, j] = h
         fd = (potf(qf + e)[0] - potf(qf - e)[0]) / (2 * h)
-        assert torch.allclose(dUf[:, j], fd, rtol=2e-4, atol=2e-4), j
+        assert torch.allclose(dUf[:, j], fd, rtol=1e-3, atol=1e-3), j
     prior = Predictive(inf.regression, num_samples=50)(3)["y_pred"]
     assert prior.shape == (50, n) and torch.isfinite(prior).all()
     post = inf.gp_run_mcmc(7, inf.x[inf.obs_idx], inf.y[inf.obs_idx], model=inf.gp_regression)
@@ -262,7 +262,9 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
         monkeypatch.setattr(parallel, "dist_info", lambda r=r: (r, 2))
         part = inf.gp_run_mcmc(7, inf.x[inf.obs_idx], inf.y[inf.obs_idx], model=inf.gp_regression)["f"]
         assert inf.chain_ids == [r, r + 2] and part.shape == (40, 12)
-        assert torch.allclose(part.reshape(2, 20, 12), whole[[r, r + 2]], rtol=1e-9, atol=1e-12)
+        # same start, momenta and uniforms per chain; the batch shape changes the order of the split-K
+        # sums inside gpvae_mvn_logp, and 50 HMC iterations amplify that rounding: close, not bit-equal
+        assert (part.reshape(2, 20, 12) - whole[[r, r + 2]]).abs().max().item() < 1e-3
     monkeypatch.undo()
     # VAE-prior model
     nz, h1, h0 = 6, 9, 12
