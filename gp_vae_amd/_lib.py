@@ -53,6 +53,7 @@ SIGNATURES = {
     "gpvae_decoder_workspace_bytes": (_i64, [_i, _i64, _i64, _i, _i, _i]),
     "gpvae_decoder_fwd": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gpvae_decoder_vjp": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpvae_decoder_vjp_static": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

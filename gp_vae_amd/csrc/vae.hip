@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include "gemm_tile.hpp"
 
 namespace gpvae {
@@ -985,6 +986,66 @@ extern "C" int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_
   if (int rc = check_dims("gpvae_decoder_vjp", dtype, chains, n, h0, h1, z)) return rc;
   if (chains == 0) return 0;
   GPVAE_REQUIRE(dec_params && Z && dF && dZ && work, 8, "gpvae_decoder_vjp: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32
+             ? run_decoder<float>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work)
+             : run_decoder<double>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work);
+}
+
+// ---- the one entry point that takes no workspace and allocates nothing ------------------------------
+// For callers that cannot allocate or carry a workspace: code under HIP graph capture, tight MCMC /
+// serving loops, harnesses that forbid hipMalloc.  Same kernels as gpvae_decoder_vjp; the scratch
+// (D1 | D2 | dD2, chains * (h1 + 2 h0) elements) is a file-scope device array, one copy per GPU for
+// the life of the process.  In host code the array's NAME is only a stand-in: its device address is
+// looked up once per device with hipGetSymbolAddress and only that pointer is handed to kernels and
+// memsets.  Every call on a GPU shares that GPU's array (calls that overlap on one GPU race); what
+// must start from zero (dD2, the split-K accumulator) is cleared by the call itself.
+static_assert(GPVAE_STATIC_SCRATCH_BYTES == (4 << 20), "include/gpvae.h states 4 MiB per GPU");
+static __device__ __align__(256) unsigned char scratch[GPVAE_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices] = {};
+
+// device address of `scratch` on the CURRENT device (looked up once per device)
+int static_scratch(void **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    gpvae::set_error("gpvae_decoder_vjp_static: hipGetDevice failed or device index %d out of range: %s", dev,
+                     hipGetErrorString(e));
+    return -1;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void *p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      gpvae::set_error("gpvae_decoder_vjp_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                       hipGetErrorString(e));
+      return -1;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int gpvae_decoder_vjp_static(void *stream, int dtype, int64_t chains, int64_t n, int h0,
+                                        int h1, int z, const void *dec_params, const void *Z,
+                                        const void *dF, void *dZ) {
+  if (int rc = check_dims("gpvae_decoder_vjp_static", dtype, chains, n, h0, h1, z)) return rc;
+  if (chains == 0) return 0;
+  GPVAE_REQUIRE(dec_params && Z && dF && dZ, 8, "gpvae_decoder_vjp_static: NULL pointer");
+  const int64_t need = gpvae_decoder_workspace_bytes(dtype, chains, n, h0, h1, z);
+  GPVAE_REQUIRE(need <= (int64_t)GPVAE_STATIC_SCRATCH_BYTES, 3,
+                "gpvae_decoder_vjp_static: chains * (h1 + 2 h0) * sizeof(T) = %lld bytes exceeds the static "
+                "scratch of %lld bytes; use gpvae_decoder_vjp with a caller workspace",
+                (long long)need, (long long)GPVAE_STATIC_SCRATCH_BYTES);
+  void *work = nullptr;
+  if (static_scratch(&work) != 0) return -1;
   hipStream_t st = (hipStream_t)stream;
   return dtype == GPVAE_F32
              ? run_decoder<float>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work)

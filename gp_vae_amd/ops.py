@@ -420,3 +420,18 @@ def decoder_vjp(dec_params, Z, dF, h0, h1):
     check(lib.gpvae_decoder_vjp(_stream(), _dt(Z), C_, n, h0, h1, z, _p(dec_params), _p(Z), _p(dF),
                                 _p(dZ), _p(_dec_work(lib, Z, n, h0, h1, z))), "gpvae_decoder_vjp")
     return dZ
+
+
+def decoder_vjp_static(dec_params, Z, dF, h0, h1, out=None):
+    """decoder_vjp through gpvae_decoder_vjp_static: no workspace, no allocation inside the library
+    (its scratch is a 4 MiB static device array per GPU; calls that overlap on one GPU race).  Pass
+    `out` to keep this wrapper allocation-free too."""
+    _dev(dec_params, Z, dF, out)
+    if not (Z.is_contiguous() and dF.is_contiguous()):
+        raise GpvaeError("decoder_vjp_static: Z and dF must be contiguous")
+    C_, z = Z.shape
+    n = dF.shape[1]
+    dZ = torch.empty_like(Z) if out is None else out
+    check(_lib.load().gpvae_decoder_vjp_static(_stream(), _dt(Z), C_, n, h0, h1, z, _p(dec_params), _p(Z),
+                                               _p(dF), _p(dZ)), "gpvae_decoder_vjp_static")
+    return dZ

@@ -207,6 +207,17 @@ int gpvae_decoder_fwd(void *stream, int dtype, int64_t chains, int64_t n, int h0
 int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
                       const void *dec_params, const void *Z, const void *dF, void *dZ, void *work);
 
+/* ---- the same VJP with no workspace argument and no allocation ------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate or carry a workspace: code
+ * under HIP graph capture, tight MCMC / serving loops, harnesses that forbid hipMalloc.  Same kernels
+ * and results as gpvae_decoder_vjp; the scratch (chains * (h1 + 2 h0) elements + 256 bytes) lives in
+ * a static device array of GPVAE_STATIC_SCRATCH_BYTES = 4 MiB per GPU, held until the process ends.  Larger problems are rejected with -3 and a message.  Calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two threads) race — serialise them.  The first
+ * call on each device looks the array's address up (hipGetSymbolAddress): make it outside a capture. */
+#define GPVAE_STATIC_SCRATCH_BYTES (4 << 20)
+int gpvae_decoder_vjp_static(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1,
+                             int z, const void *dec_params, const void *Z, const void *dF, void *dZ);
+
 #ifdef __cplusplus
 }
 #endif

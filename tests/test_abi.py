@@ -32,7 +32,7 @@ def test_exported_symbols_equal_declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = header_symbols()
-    assert len(names) == 25
+    assert len(names) == 26
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
@@ -72,6 +72,11 @@ def test_argument_validation_without_a_gpu():
     assert lib.gpvae_draw_batched(null, 0, 0, 4, null, 0, 0, null, 0, null, 0, null, null, 0, null, 0) == 0
     assert lib.gpvae_encoder_fwd(null, 0, 4, 8, 2, 2, 2, null, null, 8, null, null, null, null, null) == -8
     assert lib.gpvae_encoder_fwd(null, 0, 0, 8, 2, 2, 2, null, null, 8, null, null, null, null, null) == 0
+    # the no-allocation VJP rejects what its 4 MiB static scratch cannot hold, before touching a GPU
+    one = C.c_void_p(16)
+    assert lib.gpvae_decoder_vjp_static(null, 0, 1 << 20, 300, 35, 30, 10, one, one, one, one) == -3
+    assert b"static scratch" in lib.gpvae_last_error()
+    assert lib.gpvae_decoder_vjp_static(null, 0, 0, 300, 35, 30, 10, null, null, null, null) == 0
 
 
 def test_size_queries():
