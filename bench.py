@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_F64_MFMA_TFLOPS = 78.6   # dense f64 matrix peak
 PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 GRID = 64
 N = GRID * GRID
 B = 4096
@@ -92,14 +93,16 @@ def cpu_baseline(steps=12, budget_s=12.0):
                       "normals pre-generated, %.1f s" % (done, t_used)}
 
 
-def pmc_traffic():
-    """HBM bytes per draw launch from the committed PMC passes (profiles/r01_draw_pmc.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/prof_draw.py at this shape, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_draw_pmc.json")
+def pmc_traffic(b3):
+    """HBM bytes per draw launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of tools/prof_draw.py at this shape, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950): profiles/r02_draw_b3_pmc.json for the bf16 x 3 kernel, r01_draw_pmc.json for
+    the f32-MFMA kernel.  bench.py cannot collect counters itself; null when no pass is committed."""
+    name = "r02_draw_b3_pmc.json" if b3 else "r01_draw_pmc.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"]), "profiles/r01_draw_pmc.json"
+            return float(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + name
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -281,6 +284,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
+    ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
+                    help="matrix pipe of the float32 draws: bf16x3 (default where shapes allow) or the f32 MFMA")
     ap.add_argument("--force-collective", action="store_true",
                     help="single GPU: create a one-rank RCCL group and run the per-step all-reduce anyway")
     ap.add_argument("--dry-run", action="store_true",
@@ -315,7 +320,7 @@ def main():
     dev = torch.device("cuda", local)
     x = torch.tensor(grid_points(), device=dev)
     eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, overlap=not args.no_overlap,
-                     hyper_sampler=bench_hyper, group=args.group)
+                     hyper_sampler=bench_hyper, group=args.group, mfma=args.mfma)
     state = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
 
     def barrier():
@@ -365,7 +370,22 @@ def main():
 
     if rank == 0:
         flop = float(N) * N * B  # algorithmic: n^2 * B  (draw TRMM)
-        achieved = flop / (draw_ms * 1e-3) / 1e12 if draw_ms else None
+        f32_equiv = flop / (draw_ms * 1e-3) / 1e12 if draw_ms else None
+        if eng.b3:
+            # bf16 x 3: six bf16 piece products per float product are ISSUED — the roofline counts those
+            # against the dense bf16 peak; the f32-equivalent rate (n^2 B / t) is quoted beside it
+            roof = {"kernel": "draw_b3_kernel (Y = E L^T + sigma E', bf16 x 3: f32-accurate, f32 accumulate)",
+                    "mfma": "bf16x3", "bound": "mfma", "achieved": 6 * f32_equiv if f32_equiv else None,
+                    "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6 * f32_equiv / PEAK_BF16_MFMA_TFLOPS if f32_equiv else None, "traffic": None,
+                    "avg_launch_ms": draw_ms, "flop_per_launch": 6 * flop, "algorithmic_flop_per_launch": flop,
+                    "f32_equivalent_tflops": f32_equiv,
+                    "f32_equivalent_frac_of_f32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS if f32_equiv else None}
+        else:
+            roof = {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "mfma": "f32", "bound": "mfma",
+                    "achieved": f32_equiv, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": f32_equiv / PEAK_F32_MFMA_TFLOPS if f32_equiv else None, "traffic": None,
+                    "avg_launch_ms": draw_ms, "flop_per_launch": flop}
         out = {
             "metric": "GP-prior VAE training draws/sec at 64x64 grid",
             "value": B * args.steps * world / elapsed,
@@ -386,12 +406,10 @@ def main():
                                    "full step gram+potrf+draw+ELBO fwd/bwd+Adam",
                        "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
                        "z_dim": DIMS[2], "parallelism": "dp%d" % world,
+                       "draw_mfma": "bf16x3" if eng.b3 else "f32",
                        "factor_stream_overlap": not args.no_overlap, "factor_group": args.group,
                        "forced_single_rank_collective": bool(args.force_collective)},
-            "roofline": {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "bound": "mfma",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
-                         "traffic": None, "avg_launch_ms": draw_ms, "flop_per_launch": flop},
+            "roofline": roof,
             "final_loss": loss_last,
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "cholesky": chol[0],
@@ -401,7 +419,7 @@ def main():
         if two_streams:
             out.update({"cholesky_two_streams": chol[3], "cholesky_batch64_two_streams": chol[4],
                         "cholesky_f64_two_streams": chol[5]})
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic()
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(eng.b3)
         if world == 1 and not args.no_extras:
             out.update(extras(ops, x, dev))
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,182 @@
+// b3.hpp — "bf16 x 3": float32-accurate tile products on the bf16 matrix pipe (gfx950).
+//
+// Every f32 operand is split EXACTLY into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 mantissa
+// bits; the split is exact while no piece underflows), and a product sum_k a_k b_k is accumulated in
+// f32 from the six piece products of weight >= 2^-16:
+//     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)          on v_mfma_f32_32x32x16_bf16.
+// The three dropped products are below 2^-24 |a||b| each; measured max |err| / sum|a b| = 7e-8 at
+// K = 4096 (tools/ub_bf16x3.hip) against 1.4e-7 for v_mfma_f32_32x32x2_f32 — float32 results at
+// 2.5x the f32 MFMA rate.  Operands must be PRE-SPLIT in memory as three planes of bf16 (splitting
+// in the k loop costs ~100 vector-ALU instructions per k-tile and thread, and vector work adds to
+// MFMA time on this chip: gemm_core.hpp).
+//
+// PipeB3: C (256 x 128 per 256-thread workgroup, 4 waves as 2 x 2, each 128 x 64) += A B^T with both
+// operands K-contiguous (rows of length >= K), one workgroup per CU (145.5 KB of LDS, 512 registers
+// per lane).  Software pipeline inside each wave (measured levers in tools/proto_draw_b3p.hip):
+//   * LDS double buffer of k-tiles of 32; image [plane][8-k chunk][row][16 B] (+32 B per chunk
+//     plane): fragment reads (4 x 16 lanes, 64 banks) and tile writes (8 x 8 lanes over a 128-byte
+//     window) are conflict-free without row padding;
+//   * per k-tile: first half = MFMAs of k16 step 0 with the reads of step 1's fragments, then the
+//     ds_writes of tile t+1, each followed by the global load of the same register for tile t+2 (a
+//     whole tile of latency cover), barrier, second half = MFMAs of step 1 with the reads of tile
+//     t+1's step-0 fragments; __builtin_amdgcn_sched_group_barrier fixes the interleave (the
+//     compiler's own schedule was 19 % slower).
+// The k range must be a multiple of 64 and at least 128 (an even number >= 4 of k-tiles).
+#pragma once
+#include "gemm_core.hpp"
+
+namespace gpvae {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int B3_TM = 256, B3_TN = 128, B3_BK = 32;
+
+// exact three-way split of a float into bf16 pieces (round-to-nearest each time; the remainders are
+// exactly representable, so hi + mid + lo == v bit for bit unless a piece underflows)
+__device__ __forceinline__ void split3_bf16(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+  // v must be the ROUNDED float: without this the compiler contracts the producer's last multiply
+  // into the subtraction below (fma) and the pieces sum to the unrounded product instead
+  asm volatile("" : "+v"(v));
+  h = (__bf16)v;
+  const float r1 = v - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+struct PipeB3 {
+  static constexpr int WFM = 4, WFN = 2;  // 32 x 32 MFMA tiles per wave: 128 x 64
+  static constexpr int PAD = 32;
+  static constexpr int CPA = B3_TM * 16 + PAD, CPB = B3_TN * 16 + PAD;  // bytes per (plane, chunk)
+  static constexpr int A_BYTES = 12 * CPA, STAGE = 12 * (CPA + CPB);
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int NQA = 12, NQB = 6;  // 16-byte vectors per thread and k-tile
+  static constexpr int LEAD = 6;
+
+  i32x4_t pre[NQA + NQB];
+  bf16x8_t fa[2][3][WFM], fb[2][3][WFN];
+  f32x16 acc[WFM][WFN];
+  i32x4_t rsA[3], rsB[3];  // per plane: resource at the tile's first row
+  int voffA, voffB;        // per-lane byte offset of the loads (row tid/4, chunk tid%4)
+  int lda2, ldb2;          // row strides in bytes (scalar)
+  int wr_a, wr_b;          // per-lane LDS byte offsets of the tile writes
+  int rd_a, rd_b;          // per-lane LDS byte offsets of the fragment reads
+
+  // A3 / B3: plane 0 of the operand at the tile's first row and k = 0; planes psA / psB ELEMENTS apart
+  __device__ __forceinline__ void init(const __bf16 *A3, int64_t lda, int64_t psA, const __bf16 *B3,
+                                       int64_t ldb, int64_t psB, int tid, int wm, int wn) {
+    const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      rsA[p] = make_buffer_rsrc(A3 + p * psA);
+      rsB[p] = make_buffer_rsrc(B3 + p * psB);
+    }
+    lda2 = __builtin_amdgcn_readfirstlane((int)(lda * 2));
+    ldb2 = __builtin_amdgcn_readfirstlane((int)(ldb * 2));
+    voffA = (tid >> 2) * (int)(lda * 2) + (tid & 3) * 16;
+    voffB = (tid >> 2) * (int)(ldb * 2) + (tid & 3) * 16;
+    wr_a = (tid & 3) * CPA + (tid >> 2) * 16;
+    wr_b = A_BYTES + (tid & 3) * CPB + (tid >> 2) * 16;
+    rd_a = h * CPA + (wm + r) * 16;
+    rd_b = A_BYTES + h * CPB + (wn + r) * 16;
+  }
+  // operand tiles need rows within 2 GiB of the tile's first row
+  __host__ __device__ static bool usable(int64_t lda, int64_t ldb) {
+    return (int64_t)B3_TM * lda * 2 < ((int64_t)1 << 31) && (int64_t)B3_TN * ldb * 2 < ((int64_t)1 << 31);
+  }
+
+  __device__ __forceinline__ void gload(int k0) {
+#pragma unroll
+    for (int q = 0; q < NQA; ++q)
+      pre[q] = raw_buffer_load_b128(rsA[q >> 2], voffA, (q & 3) * 64 * lda2 + k0 * 2, 0);
+#pragma unroll
+    for (int q = 0; q < NQB; ++q)
+      pre[NQA + q] = raw_buffer_load_b128(rsB[q >> 1], voffB, (q & 1) * 64 * ldb2 + k0 * 2, 0);
+  }
+  template <int BUF> __device__ __forceinline__ void lstore(unsigned char *lds) {
+#pragma unroll
+    for (int q = 0; q < NQA; ++q)
+      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_a + (q >> 2) * 4 * CPA + (q & 3) * 1024) = pre[q];
+#pragma unroll
+    for (int q = 0; q < NQB; ++q)
+      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_b + (q >> 1) * 4 * CPB + (q & 1) * 1024) = pre[NQA + q];
+  }
+  template <int BUF, int S> __device__ __forceinline__ void read_sub(const unsigned char *lds) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int f = 0; f < WFM; ++f)
+        fa[S][p][f] = *reinterpret_cast<const bf16x8_t *>(lds + BUF * STAGE + rd_a + (p * 4 + 2 * S) * CPA + f * 512);
+#pragma unroll
+      for (int f = 0; f < WFN; ++f)
+        fb[S][p][f] = *reinterpret_cast<const bf16x8_t *>(lds + BUF * STAGE + rd_b + (p * 4 + 2 * S) * CPB + f * 512);
+    }
+  }
+  template <int S> __device__ __forceinline__ void mma_sub() {
+#pragma unroll
+    for (int fm = 0; fm < WFM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < WFN; ++fn) {
+        f32x16 c = acc[fm][fn];  // smallest products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][2][fn], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][fm], fb[S][1][fn], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][2][fm], fb[S][0][fn], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][1][fn], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][fm], fb[S][0][fn], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][0][fn], c, 0, 0, 0);
+        acc[fm][fn] = c;
+      }
+  }
+#define GPVAE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+  // k-tile in buffer CUR.  HAS1 / HAS2: tiles t+1 / t+2 exist.
+  template <int CUR, bool HAS1, bool HAS2>
+  __device__ __forceinline__ void tile(unsigned char *lds, int k0) {
+    constexpr int NXT = CUR ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+    read_sub<CUR, 1>(lds);
+    if (HAS1) lstore<NXT>(lds);
+    if (HAS2) gload(k0 + 2 * B3_BK);
+    mma_sub<0>();
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }  // MFMA, DS read
+    GPVAE_SGB(0x008, LEAD);
+    if (HAS1) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        GPVAE_SGB(0x008, 1);
+        GPVAE_SGB(0x200, 1);            // DS write
+        if (HAS2) GPVAE_SGB(0x020, 1);  // VMEM read
+      }
+    }
+    GPVAE_SGB(0x008, 48);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (HAS1) read_sub<NXT, 0>(lds);
+    mma_sub<1>();
+    if (HAS1) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }
+    }
+    GPVAE_SGB(0x008, 48);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef GPVAE_SGB
+
+  // acc += A[:, kbeg:kend) B[:, kbeg:kend)^T; (kend - kbeg) a multiple of 64 and >= 128
+  __device__ __forceinline__ void run(unsigned char *lds, int kbeg, int kend) {
+    const int nt = (kend - kbeg) / B3_BK;  // even, >= 4
+    gload(kbeg);
+    lstore<0>(lds);
+    gload(kbeg + B3_BK);
+    __syncthreads();
+    read_sub<0, 0>(lds);
+    int k0 = kbeg;
+    for (int i = 0; i < (nt - 2) / 2; ++i, k0 += 2 * B3_BK) {
+      tile<0, true, true>(lds, k0);
+      tile<1, true, true>(lds, k0 + B3_BK);
+    }
+    tile<0, true, false>(lds, k0);
+    tile<1, false, false>(lds, k0 + B3_BK);
+  }
+};
+
+}  // namespace gpvae

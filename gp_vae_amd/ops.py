@@ -237,6 +237,55 @@ def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=No
     return out
 
 
+# ---- bf16 x 3 (b3) operands: three bf16 planes that sum to the float exactly --------------------------
+def split_b3(X, lower=False, out=None):
+    """float32 X [rows, cols] or [batch, rows, cols] -> bf16 planes [3, rows, cols] / [batch, 3, rows, cols]
+    (lower: zeros above the diagonal)."""
+    _dev(X, out)
+    if X.dtype != torch.float32 or X.stride(-1) != 1:
+        raise GpvaeError("split_b3: X must be float32 with unit column stride")
+    X3 = X if X.dim() == 3 else X.unsqueeze(0)
+    batch, rows, cols = X3.shape
+    if out is None:
+        out = torch.empty((batch, 3, rows, cols), dtype=torch.bfloat16, device=X.device)
+    o = out.view(batch, 3, rows, cols)
+    check(_lib.load().gpvae_split_b3(_stream(), rows, cols, batch, _p(X3), X3.stride(1), X3.stride(0),
+                                     1 if lower else 0, _p(o), o.stride(2), o.stride(1), o.stride(0)),
+          "gpvae_split_b3")
+    return o if X.dim() == 3 else o[0]
+
+
+def randn_b3(shape, device="cuda", seed=0, stream_id=0, out=None):
+    """The float32 normals of randn(shape, seed, stream_id) as bf16 planes [3, *shape]."""
+    if out is None:
+        out = torch.empty((3,) + tuple(shape), dtype=torch.bfloat16, device=device)
+    _dev(out)
+    if not out.is_contiguous() or out.dtype != torch.bfloat16 or out.shape[0] != 3:
+        raise GpvaeError("randn_b3: out must be a contiguous bfloat16 [3, ...] tensor")
+    count = out[0].numel()
+    check(_lib.load().gpvae_randn_b3(_stream(), count, int(seed), int(stream_id), _p(out), count),
+          "gpvae_randn_b3")
+    return out
+
+
+def draw_b3_supported(n, nb):
+    return bool(_lib.load().gpvae_draw_b3_supported(int(n), int(nb)))
+
+
+def draw_b3(L3, E3, E2=None, sigma=None, want_f=False, out=None):
+    """Y = E L^T (+ sigma*E2) from b3 operands: L3 [3,n,n] (zeros above the diagonal), E3 [3,nb,n]
+    (bf16 planes), E2 [nb,n] float32.  Returns Y or (F, Y), float32."""
+    _dev(L3, E3, E2, out)
+    n, nb = L3.shape[1], E3.shape[1]
+    Y = torch.empty((nb, n), dtype=torch.float32, device=L3.device) if out is None else out
+    F = torch.empty((nb, n), dtype=torch.float32, device=L3.device) if want_f else None
+    sig = scalar(sigma, Y) if E2 is not None else None
+    check(_lib.load().gpvae_draw_b3(_stream(), n, nb, _p(L3), L3.stride(1), L3.stride(0), _p(E3), E3.stride(1),
+                                    E3.stride(0), _p(E2), E2.stride(0) if E2 is not None else 0, _p(sig),
+                                    _p(F), F.stride(0) if want_f else 0, _p(Y), Y.stride(0)), "gpvae_draw_b3")
+    return (F, Y) if want_f else Y
+
+
 # ---- a9 kriging ---------------------------------------------------------------------------------------
 def krig_predict(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi=None):
     """(mean, sample, var) at x_test given observations; literal gp_prediction arithmetic.

@@ -214,7 +214,7 @@ class StepEngine():
     draw/ELBO/Adam chain; 2 x group factor slots live in HBM (group=8, n=4096, f32: 1 GiB)."""
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
-                 hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2):
+                 hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2, mfma="auto"):
         if kernel is not exp_kernel2:
             # the engine calls gpvae_gram_se itself: another kernel would silently train on SE
             raise NotImplementedError("StepEngine builds its Gram matrices with gpvae_gram_se (exp_kernel2); "
@@ -252,7 +252,18 @@ class StepEngine():
         self.info_fail = torch.zeros(1, dtype=torch.int32, device=dev)  # factors reported not PD so far
         wbytes = _lib.load().gpvae_potrf_workspace_bytes(_dt(self.x), n, 0, G)
         self.pwork = [torch.empty(max(16, wbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.E = torch.empty((B, n), dtype=dtype, device=dev)
+        # float32 draws run on the bf16 matrix pipe when the shapes allow ("bf16 x 3": exact 3-way bf16
+        # split of both operands, six piece products, f32 accumulation — float32-accurate at 2.5x the f32
+        # MFMA rate, csrc/b3.hpp): E is generated straight as bf16 planes, L is split on the factor stream
+        if mfma not in ("auto", "f32", "bf16x3"):
+            raise ValueError("mfma must be 'auto', 'f32' or 'bf16x3'")
+        self.b3 = mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
+        if mfma == "bf16x3" and not self.b3:
+            raise GpvaeError("bf16x3 draws need float32, n % 128 == 0 and batch_size % 256 == 0")
+        if self.b3:
+            self.E3 = torch.empty((3, B, n), dtype=torch.bfloat16, device=dev)
+            self.L3buf = [torch.empty((G, 3, n, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+        self.E = None if self.b3 else torch.empty((B, n), dtype=dtype, device=dev)
         self.E2 = torch.empty((B, n), dtype=dtype, device=dev)
         # two draw buffers: step t+1 is drawn while step t's gradient all-reduce is in flight
         self.Ybuf = [torch.empty((B, n), dtype=dtype, device=dev) for _ in range(2)]
@@ -297,6 +308,8 @@ class StepEngine():
                                   0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
                   "gpvae_potrf")
             self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
+            if self.b3:  # the factors as bf16 planes, zeros above the diagonal (one pass, factor stream)
+                ops.split_b3(K[:g], lower=True, out=self.L3buf[slot][:g])
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
@@ -305,7 +318,10 @@ class StepEngine():
         main = torch.cuda.current_stream()
         if self.overlap and i == 0:
             main.wait_event(self.ev_ready[slot])
-        ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
+        if self.b3:
+            ops.randn_b3(None, out=self.E3, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
+        else:
+            ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
         ops.randn(None, out=self.E2, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 2))
         ops.randn(None, out=self.ezbuf[buf], seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
         K = self.Kbuf[slot][i]
@@ -314,9 +330,14 @@ class StepEngine():
         if self.draw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
-        check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
-                             _p(self.E2), self.n, _p(sig), None, 0, _p(self.Ybuf[buf]), self.n),
-              "gpvae_draw")
+        if self.b3:
+            L3, n = self.L3buf[slot][i], self.n
+            check(lib.gpvae_draw_b3(_stream(), n, self.B, _p(L3), n, n * n, _p(self.E3), n, self.B * n,
+                                    _p(self.E2), n, _p(sig), None, 0, _p(self.Ybuf[buf]), n), "gpvae_draw_b3")
+        else:
+            check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
+                                 _p(self.E2), self.n, _p(sig), None, 0, _p(self.Ybuf[buf]), self.n),
+                  "gpvae_draw")
         if self.draw_events is not None:
             ev[1].record(main)
             self.draw_events.append(ev)

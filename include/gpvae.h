@@ -119,6 +119,32 @@ int gpvae_draw_batched(void *stream, int dtype, int64_t n, int64_t nb, const voi
 int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
                 void *out);
 
+/* ---- a3/a4 on the bf16 matrix pipe ("bf16 x 3"): float32 results at 2.5x the f32 MFMA rate --------
+ * Same arithmetic contract as gpvae_draw in GPVAE_F32 (gp.py:190-194, vae.py:160-162): every float
+ * operand is split EXACTLY into three bf16 pieces held as three planes in memory, and each product is
+ * accumulated in f32 from the six piece products of weight >= 2^-16 (error 7e-8 of sum|e l|, below the
+ * f32 MFMA's own 1.4e-7; gp_vae_amd/csrc/b3.hpp).  A "b3" array of a [rows, cols] float matrix is
+ * bf16 out3[3][...]: piece p of element (i, j) at out3[p*plane + i*ld3 + j]; the pieces sum to the
+ * float bit for bit.
+ *   gpvae_split_b3   X [batch][rows, ldx] (f32) -> b3 planes; lower != 0 writes zeros above the
+ *                    diagonal (what gpvae_draw_b3 wants of a Cholesky factor).  batch b at
+ *                    X + b*strideX and out3 + b*stride3.
+ *   gpvae_randn_b3   the normals of gpvae_randn(GPVAE_F32, count, seed, stream_id) written straight
+ *                    as b3 planes (the f32 array is never materialised); count % 4 == 0.
+ *   gpvae_draw_b3    F = E L^T, Y = F + sigma*E2 from b3 operands: L3 [n, ldl] (zeros above the
+ *                    diagonal), E3 [nb, lde]; E2, F, Y as in gpvae_draw (f32).  Needs n % 128 == 0,
+ *                    nb % 256 == 0 (gpvae_draw_b3_supported); leading dimensions and plane strides
+ *                    multiples of 8, bases 16-byte aligned.  Bound: bf16 MFMA (6 n^2 nb flop issued).  */
+int gpvae_split_b3(void *stream, int64_t rows, int64_t cols, int batch, const void *X, int64_t ldx,
+                   int64_t strideX, int lower, void *out3, int64_t ld3, int64_t plane,
+                   int64_t stride3);
+int gpvae_randn_b3(void *stream, int64_t count, uint64_t seed, uint64_t stream_id, void *out3,
+                   int64_t plane);
+int gpvae_draw_b3_supported(int64_t n, int64_t nb);
+int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3, int64_t ldl, int64_t planeL,
+                  const void *E3, int64_t lde, int64_t planeE, const void *E2, int64_t lde2,
+                  const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy);
+
 /* ---- a9: kriging prediction ---------------------------------------------------------------------
  * Replaces GPInference.gp_prediction (src/model/inference.py:427-460), literal quirks kept:
  *   A = k_xx + jitter*I + sigma*I   (sigma, not sigma^2: inference.py:450)

@@ -302,3 +302,55 @@ def test_decoder_reference_shapes_and_nan_weights():
             assert rel(ops.decoder_vjp(flat, dev(Z, tdt), dev(dF, tdt), h0, h1), orc.decoder_vjp(p, Z, dF)) < tol
         bad = torch.full_like(flat, float("nan"))
         assert torch.isnan(ops.decoder_fwd(bad, dev(Z, torch.float32), n, h0, h1)).all()
+
+
+def test_b3_planes_and_draw():
+    """bf16 x 3: the planes sum to the float bit for bit (split and Philox producer), and the draw on
+    them meets gpvae_draw's float32 bar against the float64 oracle — at least as close as the f32-MFMA
+    kernel on the same inputs."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(9)
+    X = torch.tensor(rng.standard_normal((2, 130, 70)) * 10 ** rng.uniform(-6, 6, (2, 130, 70)), dtype=torch.float32, device=DEV)
+    P = ops.split_b3(X)
+    assert P.shape == (2, 3, 130, 70) and torch.equal(P.float().sum(1), X)
+    Pl = ops.split_b3(X[0, :70], lower=True)
+    assert torch.equal(Pl.float().sum(0), torch.tril(X[0, :70]))
+    E3 = ops.randn_b3((256, 384), DEV, seed=12345, stream_id=7)
+    E = ops.randn((256, 384), torch.float32, DEV, seed=12345, stream_id=7)
+    assert torch.equal(E3.float().sum(0), E)
+    assert ops.draw_b3_supported(4096, 4096) and not ops.draw_b3_supported(300, 100) and not ops.draw_b3_supported(4096, 100)
+    for n, nb in ((128, 256), (384, 256), (1024, 512)):
+        Lh = np.tril(rng.standard_normal((n, n))) * 0.1
+        E2h = rng.standard_normal((nb, n))
+        L = torch.tensor(Lh, dtype=torch.float32, device=DEV) + torch.triu(torch.full((n, n), 5.0, device=DEV), 1)
+        E3 = ops.randn_b3((nb, n), DEV, seed=3, stream_id=n)
+        Eh = E3.float().sum(0).cpu().numpy().astype(np.float64)
+        L64 = np.tril(L.cpu().numpy().astype(np.float64))
+        Fo = Eh @ L64.T
+        E2 = torch.tensor(E2h, dtype=torch.float32, device=DEV)
+        F, Y = ops.draw_b3(ops.split_b3(L, lower=True), E3, E2, 0.3, want_f=True)
+        Ff = ops.draw(L, E3.float().sum(0))  # the f32-MFMA kernel on the same floats
+        e_b3, e_f32 = rel(F, Fo), rel(Ff, Fo)
+        assert e_b3 < 1e-5 and e_b3 < 2 * e_f32 + 1e-7, (n, nb, e_b3, e_f32)
+        assert rel(Y, Fo + 0.3 * E2.cpu().numpy().astype(np.float64)) < 1e-5
+        assert rel(ops.draw_b3(ops.split_b3(L, lower=True), E3), Fo) < 1e-5
+
+
+def test_b3_draw_full_size_c3():
+    """C3 (n = B = 4096): bf16 x 3 draw against the f32-MFMA draw and a float64 product on sampled rows."""
+    from gp_vae_amd import ops
+    n = B = 4096
+    g = np.arange(0, 1, 1 / 64)
+    u, v = np.meshgrid(g, g)
+    x = torch.tensor(np.stack([u.ravel(), v.ravel()], 1), dtype=torch.float32, device=DEV)
+    K = ops.gram_se(x, x, 1.0, 0.2, 1e-3)
+    assert int(ops.potrf_(K, zero_upper=False).item()) == 0
+    E3 = ops.randn_b3((B, n), DEV, seed=1, stream_id=1)
+    E2 = ops.randn((B, n), torch.float32, DEV, seed=1, stream_id=2)
+    Y = ops.draw_b3(ops.split_b3(K, lower=True), E3, E2, 0.05)
+    E = E3.float().sum(0)
+    Yf = ops.draw(K, E, E2, 0.05)
+    rows = torch.tensor(np.random.default_rng(0).integers(0, B, 48), device=DEV)
+    want = (E[rows].double() @ torch.tril(K).double().T + 0.05 * E2[rows].double()).cpu().numpy()
+    e_b3, e_f32 = rel(Y[rows], want), rel(Yf[rows], want)
+    assert e_b3 < 1e-5 and e_b3 < 2 * e_f32 + 1e-7, (e_b3, e_f32)

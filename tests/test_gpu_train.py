@@ -52,6 +52,41 @@ def test_step_engine_matches_oracle_train_steps(tdt, ndt, tol):
     assert abs(l2 - loss_sum) <= 1e-5 * abs(loss_sum)
 
 
+def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
+    """Shapes that put the engine's draws on the bf16 matrix pipe (float32, n % 128 == 0, B % 256 == 0):
+    same float32 bar against oracle.train_step as the f32-MFMA engine, and the two engines agree."""
+    from gp_vae_amd import ops, parallel
+    from gp_vae_amd.gp import draw_hyper
+    from gp_vae_amd.vae import StepEngine, SVIState
+    n, B, dims, lr, jit = 256, 256, (20, 12, 5), 1e-3, 1e-3
+    g = np.arange(0, 1, 1 / 16)
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1)
+    keys = [(5, i) for i in range(3)]
+    res = {}
+    for mode in ("bf16x3", "f32"):
+        eng = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=torch.float32, seed=1, group=2, mfma=mode)
+        assert eng.b3 == (mode == "bf16x3")
+        p0 = {k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}
+        st = SVIState(torch.tensor(orc.flatten(p0), dtype=torch.float32, device=DEV))
+        res[mode] = (eng.run(keys, st, train=True).item(), st.params.cpu().numpy())
+    p = {k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}
+    m = {k: np.zeros_like(a) for k, a in p.items()}
+    vv = {k: np.zeros_like(a) for k, a in p.items()}
+    want = 0.0
+    for t, key in enumerate(keys, 1):
+        E, E2, ez = (ops.randn(s, torch.float32, DEV, seed=1, stream_id=parallel.philox_stream_id(0, key, i)).cpu().numpy().astype(np.float64)
+                     for i, s in ((1, (B, n)), (2, (B, n)), (3, (B, dims[2]))))
+        loss, p, m, vv = orc.train_step(p, m, vv, t, x, draw_hyper(parallel.step_rng(1, 0, key)), E, E2, ez, lr, jit)
+        want += loss
+    for mode in ("bf16x3", "f32"):
+        assert abs(res[mode][0] - want) < 2e-3 * abs(want), mode
+        assert rel(res[mode][1], orc.flatten(p)) < 2e-3, mode
+    assert abs(res["bf16x3"][0] - res["f32"][0]) < 1e-4 * abs(want)
+    with pytest.raises(Exception):
+        StepEngine(torch.tensor(np.arange(300) / 300), jit, dims, 100, lr, mfma="bf16x3")
+
+
 def test_vae_fit_reference_surface_trains():
     from gp_vae_amd.gp import GP, Predictive, exp_kernel2
     from gp_vae_amd.vae import VAE
