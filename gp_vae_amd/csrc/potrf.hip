@@ -17,7 +17,7 @@
 // "Virtual rows": rows >= n come from a second array X (m_extra rows of length n); they ride along
 // as extra chunks and come out as X L^-T — the right-hand solve kriging needs — for free.
 // Rows/cols between n and the next multiple of 64 behave as an identity block.
-#include "gemm_core.hpp"
+#include "b3.hpp"
 
 namespace gpvae {
 
@@ -264,6 +264,7 @@ template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, T *dwork,
+                                                               __bf16 *P3,
                                                                unsigned long long *stamps) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
@@ -453,6 +454,19 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
     T *rp = vr.ptr(rbase + s);
     if (rp == nullptr) continue;
     T *dst = rp + c0 + j;
+    if constexpr (sizeof(T) == 4) {
+      // rows below the outer block also go out as three bf16 planes [plane][row][256]: the operand of
+      // the bf16 x 3 trailing update (potrf_syrk_b3_kernel), pieces summing to the float exactly
+      if (P3 != nullptr && rbase + s >= cJ + NBO) {
+        __bf16 hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3_bf16(tp[e], hh[e], mm[e], ll[e]);
+        __bf16 *q = P3 + ((int64_t)b * 3 * vr.npad + (rbase + s)) * NBO + (c0 - cJ) + j;
+        *reinterpret_cast<uint64_t *>(q) = *reinterpret_cast<const uint64_t *>(hh);
+        *reinterpret_cast<uint64_t *>(q + vr.npad * NBO) = *reinterpret_cast<const uint64_t *>(mm);
+        *reinterpret_cast<uint64_t *>(q + 2 * vr.npad * NBO) = *reinterpret_cast<const uint64_t *>(ll);
+      }
+    }
     if (vcols) {
       *reinterpret_cast<V *>(dst) = t;
     } else {
@@ -600,6 +614,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
     }
 }
 
+
+// ---- the same trailing update on the bf16 matrix pipe (float32, whole outer blocks, no extra rows) ----
+// C[r][c] -= sum_k P[r][k] P[c][k] with P read as the three bf16 planes the panel launches wrote
+// (pieces sum to the float exactly; six piece products per float product, f32 accumulation: b3.hpp),
+// 256 x 128 tiles, one workgroup per CU.  The accumulators start from -C as above.  Tiles that cross
+// the diagonal (tc >= 2 tr) compute their upper part too and mask it in the store.
+// Tile p of a matrix -> (tr, tc), tc <= 2 tr + 1: row tr holds 2 tr + 2 tiles.
+struct SyrkB3Map {
+  int R, batch;   // 256-row tile rows of the trailing matrix
+  int64_t per;    // R (R + 1) tiles per matrix
+  __host__ int64_t grid() const {
+    return batch >= 8 ? 8 * (int64_t)((batch + 7) / 8) * per : (int64_t)batch * per;
+  }
+  __device__ __forceinline__ bool decode(int64_t id, int &b, int &tr, int &tc) const {
+    int64_t p;
+    if (batch >= 8) {  // XCD x owns the matrices b = x (mod 8), as in SyrkMap
+      const int xcd = (int)(id & 7);
+      const int64_t k = id >> 3;
+      const int64_t mb = k / per;
+      b = xcd + 8 * (int)mb;
+      if (b >= batch) return false;
+      p = k - mb * per;
+    } else {
+      b = (int)(id / per);
+      p = id - (int64_t)b * per;
+    }
+    int r = (int)((sqrtf(4.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((int64_t)r * (r + 1) > p) --r;
+    while ((int64_t)(r + 1) * (r + 2) <= p) ++r;
+    tr = r;
+    tc = (int)(p - (int64_t)r * (r + 1));
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
+                                                                    int64_t strideA, const __bf16 *P3,
+                                                                    int64_t npad, int64_t kend,
+                                                                    SyrkB3Map map) {
+  using M = Mfma<float>;
+  __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
+  int b, tr, tc;
+  if (!map.decode(blockIdx.x, b, tr, tc)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *Ab = A + (int64_t)b * strideA;
+  const __bf16 *Pb = P3 + (int64_t)b * 3 * npad * NBO;
+  const int64_t r0 = kend + (int64_t)tr * B3_TM, q0 = kend + (int64_t)tc * B3_TN;
+  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  PipeB3 P;
+  P.init(Pb + r0 * NBO, NBO, npad * NBO, Pb + q0 * NBO, NBO, npad * NBO, tid, wm, wn);
+  TileIO<float> io;
+  io.init(Ab + (r0 + wm) * lda + q0 + wn, lda, lane);
+  // (tried: the C tile through LDS with coalesced 16-byte loads and the first operand tile requested
+  // behind them — 8.7 instead of 8.3 ms per 32 x 4096 batch: the tile's time is its k loop, 8 k-tiles at
+  // ~3 us, not the C traffic)
+#pragma unroll
+  for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] = io.load(fm, fn, r);
+#pragma unroll
+  for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] = -P.acc[fm][fn][r];
+  P.run(lds, 0, NBO);
+  if (tc < 2 * tr) {  // wholly below the diagonal
+#pragma unroll
+    for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) io.store(fm, fn, r, -P.acc[fm][fn][r]);
+    return;
+  }
+#pragma unroll
+  for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = r0 + wm + fm * 32 + M::row(lane, r), col = q0 + wn + fn * 32 + M::col(lane);
+        if (col <= row) Ab[row * lda + col] = -P.acc[fm][fn][r];
+      }
+}
+
 // ---- finalize: zero the strict upper triangle; NaN-fill failed matrices -------------------------------
 template <typename T>
 __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_t n, int64_t npad,
@@ -623,6 +725,14 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
   }
 }
 
+// workspace: [parked diagonal blocks | bf16 planes of the current outer panel (b3 path only)]
+static inline int64_t l11_bytes(int64_t es, int64_t n, int batch) {
+  return round_up((int64_t)batch * round_up(n, NB) * NB * es, 256);
+}
+static inline bool potrf_b3_ok(bool f32, int64_t n, int64_t mx) {
+  return f32 && mx == 0 && n >= 2 * NBO && n % NBO == 0;
+}
+
 template <typename T, bool VECM>
 static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
@@ -630,6 +740,10 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
   constexpr int NCH = PanelCfg<T>::NCH;
   VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
   const int64_t Mv = vr.npad + mx;
+  // float32, whole 256-column outer blocks, no extra rows: trailing updates on the bf16 matrix pipe;
+  // the panel launches then also write their rows as bf16 planes behind the parked diagonal blocks
+  const bool b3 = potrf_b3_ok(sizeof(T) == 4, n, mx) && VECM && 128 * lda * 4 < ((int64_t)1 << 31);
+  __bf16 *P3 = b3 ? (__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)) : nullptr;
   if (hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     set_error("gpvae_potrf: hipMemsetAsync(info) failed");
     return -12;
@@ -641,7 +755,16 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
       hipLaunchKernelGGL((potrf_panel_kernel<T, VECM>), dim3((unsigned)nwg, (unsigned)batch),
                          dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work,
-                         g_stamps);
+                         P3, g_stamps);
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (b3 && kend < n) {
+        const int R = (int)((n - kend) / B3_TM);
+        const SyrkB3Map map{R, batch, (int64_t)R * (R + 1)};
+        hipLaunchKernelGGL(potrf_syrk_b3_kernel, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
+                           lda, strideA, P3, vr.npad, kend, map);
+        continue;
+      }
     }
     if (kend < n) {
       const int rt = (int)cdiv(Mv - kend, SBM), ct = (int)cdiv(n - kend, SBM);
@@ -681,11 +804,15 @@ extern "C" void gpvae_dev_set_stamps(void *p) { gpvae::g_stamps = (unsigned long
 #endif
 
 extern "C" int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch) {
-  (void)m_extra;
   // one dense 64x64 block per diagonal block and matrix: the factored diagonal blocks wait here
   // until the last launch copies them over A (see potrf_panel_kernel's store phase)
+  // ... and, for float32 problems that take the bf16 x 3 trailing update (n a multiple of 256, no extra
+  // rows), the current outer panel as three bf16 planes: batch * 3 * n * 256 * 2 bytes
   if (n <= 0 || batch <= 0) return 0;
-  return (int64_t)batch * round_up(n, NB) * NB * (dtype == GPVAE_F64 ? 8 : 4);
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  int64_t bytes = l11_bytes(es, n, batch);
+  if (potrf_b3_ok(dtype == GPVAE_F32, n, m_extra)) bytes += (int64_t)batch * 3 * round_up(n, NB) * NBO * 2;
+  return bytes;
 }
 
 extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
@@ -711,6 +838,7 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
     const int rt = (int)cdiv(round_up(n, NB) + m_extra, SBM), ct = (int)cdiv(n, SBM);
     const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 4, "gpvae_potrf: batch x tiles exceeds one launch; split the batch");
+    GPVAE_REQUIRE((int64_t)batch * 3 * round_up(n, NB) * NBO < ((int64_t)1 << 40), 4, "gpvae_potrf: batch too large");
   }
   hipStream_t st = (hipStream_t)stream;
   if (m_extra == 0) X = nullptr;
