@@ -174,12 +174,17 @@ def extras(ops, x, dev):
     st = SVIState(init_params(1024, 35, 30, 10, 1, torch.float32, dev))
     eng.run([(0, i) for i in range(32)], st, train=True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run([(1, i) for i in range(256)], st, train=True)
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / 256
+    time.sleep(2.0)  # right after the sustained MFMA load above the chip runs this light step at half speed
+    t = None         # (power management; it recovers within 2 s of idling: tools/c2exp.py)
+    for rep in (1, 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run([(rep, i) for i in range(256)], st, train=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 256
+        t = dt if t is None else min(t, dt)
     out["c2"] = {"workload": "C2: 1D n=1024, B=4096, VAE 1024-35-30-10, f32, full training step",
-                 "ms_per_step": t * 1e3, "draws_per_s": 4096 / t}
+                 "ms_per_step": t * 1e3, "draws_per_s": 4096 / t, "sample": "best of 2 runs of 256 steps"}
     del eng, st
     # C4: the n_obs = 32768 f64 factorisation (8 GiB in place), SE Gram of a 2D point set + nugget
     n4 = 32768

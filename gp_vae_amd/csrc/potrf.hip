@@ -50,6 +50,17 @@ template <typename T> struct VRows {
   }
 };
 
+// Where the bf16 planes of the factor's columns go (float32 problems on the bf16 x 3 path): piece pl of
+// element (vrow, col) of matrix b at  p[b*stride + pl*plane + vrow*ld + col - coloff].
+//   workspace mode (gpvae_potrf): only the current outer panel, [row][256], coloff = cJ, rows below
+//     the outer block only (first_row = cJ + 256);
+//   factor mode (gpvae_potrf_b3): the caller's whole L3 [n][ld3], coloff = 0, every row.
+struct B3Out {
+  __bf16 *p;
+  int64_t ld, plane, stride;
+  int whole;  // factor mode
+};
+
 template <typename T> struct PanelCfg;
 template <> struct PanelCfg<float> {
   static constexpr int BK = 32;  // k-tile of the staged update GEMM
@@ -264,7 +275,7 @@ template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, T *dwork,
-                                                               __bf16 *P3,
+                                                               B3Out o3,
                                                                unsigned long long *stamps) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
@@ -457,14 +468,14 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
     if constexpr (sizeof(T) == 4) {
       // rows below the outer block also go out as three bf16 planes [plane][row][256]: the operand of
       // the bf16 x 3 trailing update (potrf_syrk_b3_kernel), pieces summing to the float exactly
-      if (P3 != nullptr && rbase + s >= cJ + NBO) {
+      if (o3.p != nullptr && (o3.whole || rbase + s >= cJ + NBO)) {
         __bf16 hh[4], mm[4], ll[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3_bf16(tp[e], hh[e], mm[e], ll[e]);
-        __bf16 *q = P3 + ((int64_t)b * 3 * vr.npad + (rbase + s)) * NBO + (c0 - cJ) + j;
+        __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (o3.whole ? c0 : c0 - cJ) + j;
         *reinterpret_cast<uint64_t *>(q) = *reinterpret_cast<const uint64_t *>(hh);
-        *reinterpret_cast<uint64_t *>(q + vr.npad * NBO) = *reinterpret_cast<const uint64_t *>(mm);
-        *reinterpret_cast<uint64_t *>(q + 2 * vr.npad * NBO) = *reinterpret_cast<const uint64_t *>(ll);
+        *reinterpret_cast<uint64_t *>(q + o3.plane) = *reinterpret_cast<const uint64_t *>(mm);
+        *reinterpret_cast<uint64_t *>(q + 2 * o3.plane) = *reinterpret_cast<const uint64_t *>(ll);
       }
     }
     if (vcols) {
@@ -650,8 +661,8 @@ struct SyrkB3Map {
 };
 
 __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
-                                                                    int64_t strideA, const __bf16 *P3,
-                                                                    int64_t npad, int64_t kend,
+                                                                    int64_t strideA, B3Out o3,
+                                                                    int64_t cJ, int64_t kend,
                                                                     SyrkB3Map map) {
   using M = Mfma<float>;
   __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
@@ -659,11 +670,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
   if (!map.decode(blockIdx.x, b, tr, tc)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *Ab = A + (int64_t)b * strideA;
-  const __bf16 *Pb = P3 + (int64_t)b * 3 * npad * NBO;
+  const __bf16 *Pb = o3.p + (int64_t)b * o3.stride + (o3.whole ? cJ : 0);  // row 0, first panel column
   const int64_t r0 = kend + (int64_t)tr * B3_TM, q0 = kend + (int64_t)tc * B3_TN;
   const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
   PipeB3 P;
-  P.init(Pb + r0 * NBO, NBO, npad * NBO, Pb + q0 * NBO, NBO, npad * NBO, tid, wm, wn);
+  P.init(Pb + r0 * o3.ld, o3.ld, o3.plane, Pb + q0 * o3.ld, o3.ld, o3.plane, tid, wm, wn);
   TileIO<float> io;
   io.init(Ab + (r0 + wm) * lda + q0 + wn, lda, lane);
   // (tried: the C tile through LDS with coalesced 16-byte loads and the first operand tile requested
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
 // ---- finalize: zero the strict upper triangle; NaN-fill failed matrices -------------------------------
 template <typename T>
 __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_t n, int64_t npad,
-                                      const T *dwork, const int32_t *info, int flags) {
+                                      const T *dwork, const int32_t *info, int flags, B3Out o3) {
   const int b = blockIdx.z;
   T *Ab = A + (int64_t)b * strideA;
   const bool failed = (flags & GPVAE_POTRF_NAN_ON_FAIL) && info[b] != 0;
@@ -723,6 +734,27 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
     else if (in_diag) Ab[i * lda + j] = l11[(i - i0) * NB + (j - i0)];  // L11 (upper part is zero)
     else if (j > i) Ab[i * lda + j] = T(0);
   }
+  if constexpr (sizeof(T) == 4) {
+    // factor mode of the bf16 planes: the diagonal blocks (parked in dwork) go out as planes too, and
+    // the 64 x 64 block right of every EVEN diagonal block is cleared — the draw's k loop ends at the
+    // 128-column tile that holds the diagonal, so that block is all it ever reads above the diagonal
+    if (o3.p != nullptr && o3.whole && in_diag) {
+      __bf16 *q = o3.p + (int64_t)b * o3.stride;
+      const bool even = (blockIdx.y & 1) == 0 && j + NB < n;
+      for (int64_t i = i0; i < i1; ++i) {
+        __bf16 hh, mm, ll;
+        split3_bf16(failed ? dnan<float>() : l11[(i - i0) * NB + (j - i0)], hh, mm, ll);
+        q[i * o3.ld + j] = hh;
+        q[o3.plane + i * o3.ld + j] = mm;
+        q[2 * o3.plane + i * o3.ld + j] = ll;
+        if (even) {
+          q[i * o3.ld + j + NB] = (__bf16)0.f;
+          q[o3.plane + i * o3.ld + j + NB] = (__bf16)0.f;
+          q[2 * o3.plane + i * o3.ld + j + NB] = (__bf16)0.f;
+        }
+      }
+    }
+  }
 }
 
 // workspace: [parked diagonal blocks | bf16 planes of the current outer panel (b3 path only)]
@@ -736,14 +768,21 @@ static inline bool potrf_b3_ok(bool f32, int64_t n, int64_t mx) {
 template <typename T, bool VECM>
 static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
-                     void *work) {
+                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0}) {
   constexpr int NCH = PanelCfg<T>::NCH;
   VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
   const int64_t Mv = vr.npad + mx;
   // float32, whole 256-column outer blocks, no extra rows: trailing updates on the bf16 matrix pipe;
   // the panel launches then also write their rows as bf16 planes behind the parked diagonal blocks
   const bool b3 = potrf_b3_ok(sizeof(T) == 4, n, mx) && VECM && 128 * lda * 4 < ((int64_t)1 << 31);
-  __bf16 *P3 = b3 ? (__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)) : nullptr;
+  B3Out o3{nullptr, 0, 0, 0, 0};
+  if (b3) {
+    if (ext.p != nullptr) o3 = ext;  // the caller's whole-factor planes double as the panel operand
+    else o3 = B3Out{(__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)), NBO, vr.npad * NBO, 3 * vr.npad * NBO, 0};
+  } else if (ext.p != nullptr) {
+    set_error("gpvae_potrf_b3: needs 16-byte aligned rows (lda %% 4 == 0) and 128*lda*4 < 2^31");
+    return -5;
+  }
   if (hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st) != hipSuccess) {
     set_error("gpvae_potrf: hipMemsetAsync(info) failed");
     return -12;
@@ -755,14 +794,14 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
       hipLaunchKernelGGL((potrf_panel_kernel<T, VECM>), dim3((unsigned)nwg, (unsigned)batch),
                          dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work,
-                         P3, g_stamps);
+                         o3, g_stamps);
     }
     if constexpr (sizeof(T) == 4) {
       if (b3 && kend < n) {
         const int R = (int)((n - kend) / B3_TM);
         const SyrkB3Map map{R, batch, (int64_t)R * (R + 1)};
         hipLaunchKernelGGL(potrf_syrk_b3_kernel, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                           lda, strideA, P3, vr.npad, kend, map);
+                           lda, strideA, o3, cJ, kend, map);
         continue;
       }
     }
@@ -776,7 +815,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
                      dim3(flags ? (unsigned)cdiv(n, 256) : 1u, (unsigned)cdiv(n, NB), (unsigned)batch),
                      dim3(flags ? 256 : NB), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
-                     flags);
+                     flags, o3);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
 }
@@ -785,14 +824,14 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
 template <typename T>
 static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
-                     void *work) {
+                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0}) {
   constexpr int VEC = VecT<T>::N;
   const bool vec = kc_vec_ok<T>(A, lda) && (strideA % VEC == 0) &&
                    (mx == 0 || (kc_vec_ok<T>(X, ldx) && (strideX % VEC == 0)));
   return vec ? run_potrf_v<T, true>(st, n, batch, A, lda, strideA, mx, X, ldx, strideX, info, flags,
-                                    work)
+                                    work, ext)
              : run_potrf_v<T, false>(st, n, batch, A, lda, strideA, mx, X, ldx, strideX, info,
-                                     flags, work);
+                                     flags, work, ext);
 }
 
 }  // namespace gpvae
@@ -847,4 +886,40 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
                                 work)
              : run_potrf<double>(st, n, batch, A, lda, strideA, m_extra, X, ldx, strideX, info,
                                  flags, work);
+}
+
+// float32 factorisation that also leaves the factor as bf16 x 3 planes (the operand gpvae_draw_b3 wants):
+// the planes are written by the panel launches as they go and serve as the operand of the bf16 x 3
+// trailing updates, so no separate split pass over L is needed.
+extern "C" int gpvae_potrf_b3_supported(int64_t n) { return potrf_b3_ok(true, n, 0) ? 1 : 0; }
+
+extern "C" int64_t gpvae_potrf_b3_workspace_bytes(int64_t n, int batch) {
+  if (n <= 0 || batch <= 0) return 0;
+  return l11_bytes(4, n, batch);
+}
+
+extern "C" int gpvae_potrf_b3(void *stream, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                              int32_t *info, int flags, void *work, void *L3, int64_t ld3,
+                              int64_t plane, int64_t stride3) {
+  GPVAE_REQUIRE(n >= 0, 2, "gpvae_potrf_b3: n < 0");
+  GPVAE_REQUIRE(batch >= 0 && batch <= 65535, 3, "gpvae_potrf_b3: batch out of range [0,65535]");
+  if (n == 0 || batch == 0) return 0;
+  GPVAE_REQUIRE(potrf_b3_ok(true, n, 0), 2, "gpvae_potrf_b3: n must be a multiple of 256 and >= 512 (gpvae_potrf_b3_supported)");
+  GPVAE_REQUIRE(A && aligned16(A), 4, "gpvae_potrf_b3: A is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(lda >= n && lda % 4 == 0, 5, "gpvae_potrf_b3: lda < n or not a multiple of 4");
+  GPVAE_REQUIRE(batch == 1 || (strideA >= n * lda && strideA % 4 == 0), 6, "gpvae_potrf_b3: strideA < n*lda or not a multiple of 4");
+  GPVAE_REQUIRE(info, 7, "gpvae_potrf_b3: info is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 9, "gpvae_potrf_b3: work is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(L3 && aligned16(L3), 10, "gpvae_potrf_b3: L3 is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(ld3 >= n && ld3 % 8 == 0, 11, "gpvae_potrf_b3: ld3 < n or not a multiple of 8");
+  GPVAE_REQUIRE(plane >= n * ld3 && plane % 8 == 0, 12, "gpvae_potrf_b3: plane < n*ld3 or not a multiple of 8");
+  GPVAE_REQUIRE(batch == 1 || (stride3 >= 3 * plane && stride3 % 8 == 0), 13, "gpvae_potrf_b3: stride3 < 3*plane or not a multiple of 8");
+  GPVAE_REQUIRE(PipeB3::usable(ld3, ld3), 11, "gpvae_potrf_b3: ld3 too large");
+  {
+    const int rt = (int)cdiv(round_up(n, NB), SBM), ct = (int)cdiv(n, SBM);
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 3, "gpvae_potrf_b3: batch x tiles exceeds one launch; split the batch");
+  }
+  return run_potrf<float>((hipStream_t)stream, n, batch, A, lda, strideA, 0, nullptr, 0, 0, info, flags, work,
+                          B3Out{(__bf16 *)L3, ld3, plane, stride3, 1});
 }

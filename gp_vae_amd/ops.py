@@ -255,6 +255,33 @@ def split_b3(X, lower=False, out=None):
     return o if X.dim() == 3 else o[0]
 
 
+def potrf_b3_supported(n):
+    return bool(_lib.load().gpvae_potrf_b3_supported(int(n)))
+
+
+def potrf_b3_(A, L3=None, zero_upper=False, nan_on_fail=False, work=None, info=None):
+    """In-place float32 Cholesky of A [batch,n,n] (or [n,n]) that also leaves the factor as bf16 x 3 planes
+    L3 [batch,3,n,n] for draw_b3 (written by the panel launches themselves: no split pass).
+    Returns (info, L3)."""
+    _dev(A, L3)
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    batch, n = A3.shape[0], A3.shape[1]
+    if A3.dtype != torch.float32 or A3.shape[2] != n or A3.stride(2) != 1:
+        raise GpvaeError("potrf_b3_: A must be float32 [batch,n,n] with unit column stride")
+    if L3 is None:
+        L3 = torch.empty((batch, 3, n, n), dtype=torch.bfloat16, device=A.device)
+    o = L3.view(batch, 3, n, n)
+    if info is None:
+        info = torch.empty((batch,), dtype=torch.int32, device=A.device)
+    lib = _lib.load()
+    if work is None:
+        work = torch.empty(max(16, lib.gpvae_potrf_b3_workspace_bytes(n, batch)), dtype=torch.uint8, device=A.device)
+    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    check(lib.gpvae_potrf_b3(_stream(), n, batch, _p(A3), A3.stride(1), A3.stride(0), _p(info), flags, _p(work),
+                             _p(o), o.stride(2), o.stride(1), o.stride(0)), "gpvae_potrf_b3")
+    return info, (o if A.dim() == 3 else o[0])
+
+
 def randn_b3(shape, device="cuda", seed=0, stream_id=0, out=None):
     """The float32 normals of randn(shape, seed, stream_id) as bf16 planes [3, *shape]."""
     if out is None:

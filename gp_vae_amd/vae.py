@@ -257,9 +257,10 @@ class StepEngine():
         # MFMA rate, csrc/b3.hpp): E is generated straight as bf16 planes, L is split on the factor stream
         if mfma not in ("auto", "f32", "bf16x3"):
             raise ValueError("mfma must be 'auto', 'f32' or 'bf16x3'")
-        self.b3 = mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
+        self.b3 = (mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
+                   and ops.potrf_b3_supported(n))
         if mfma == "bf16x3" and not self.b3:
-            raise GpvaeError("bf16x3 draws need float32, n % 128 == 0 and batch_size % 256 == 0")
+            raise GpvaeError("bf16x3 draws need float32, n % 256 == 0, n >= 512 and batch_size % 256 == 0")
         if self.b3:
             self.E3 = torch.empty((3, B, n), dtype=torch.bfloat16, device=dev)
             self.L3buf = [torch.empty((G, 3, n, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]
@@ -304,12 +305,15 @@ class StepEngine():
                                     _p(self.x), g, _p(hd[0]), _p(hd[1]), float(self.jitter), _p(K),
                                     self.ld, self.n * self.ld), "gpvae_gram_se")
             # the draw masks the strict upper triangle itself: no zeroing / NaN-fill pass needed
-            check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
-                                  0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
-                  "gpvae_potrf")
+            if self.b3:  # factor + its bf16 planes in one sweep (the panel launches write the planes)
+                check(lib.gpvae_potrf_b3(_stream(), self.n, g, _p(K), self.ld, self.n * self.ld, _p(self.info[slot]),
+                                         0, _p(self.pwork[slot]), _p(self.L3buf[slot]), self.n, self.n * self.n,
+                                         3 * self.n * self.n), "gpvae_potrf_b3")
+            else:
+                check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
+                                      0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
+                      "gpvae_potrf")
             self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
-            if self.b3:  # the factors as bf16 planes, zeros above the diagonal (one pass, factor stream)
-                ops.split_b3(K[:g], lower=True, out=self.L3buf[slot][:g])
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
@@ -374,7 +378,10 @@ class StepEngine():
         if not keys:
             return self.loss_sum
         self.loss_steps = torch.zeros(len(keys), dtype=self.dtype, device=self.x.device)
-        groups = [keys[i:i + self.G] for i in range(0, len(keys), self.G)]
+        # the first group is exposed (nothing to overlap it with): half a group gets the first draw
+        # started sooner and is still long enough (G/2 steps of draws) to hide the next full group
+        g0 = max(1, self.G // 2) if len(keys) > self.G else self.G
+        groups = [keys[:g0]] + [keys[i:i + self.G] for i in range(g0, len(keys), self.G)]
         if self.overlap:
             for s in range(2):
                 self.ev_free[s].record(torch.cuda.current_stream())

@@ -134,7 +134,19 @@ int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t 
  *   gpvae_draw_b3    F = E L^T, Y = F + sigma*E2 from b3 operands: L3 [n, ldl] (zeros above the
  *                    diagonal), E3 [nb, lde]; E2, F, Y as in gpvae_draw (f32).  Needs n % 128 == 0,
  *                    nb % 256 == 0 (gpvae_draw_b3_supported); leading dimensions and plane strides
- *                    multiples of 8, bases 16-byte aligned.  Bound: bf16 MFMA (6 n^2 nb flop issued).  */
+ *                    multiples of 8, bases 16-byte aligned.  Bound: bf16 MFMA (6 n^2 nb flop issued).
+ *   gpvae_potrf_b3   gpvae_potrf(GPVAE_F32, no extra rows) that ALSO leaves the factor as b3 planes
+ *                    L3 [batch][3][n, ld3] (zeros wherever gpvae_draw_b3 reads above the diagonal):
+ *                    the panel launches write the planes as they go and the bf16 x 3 trailing updates
+ *                    read them, so the draw's operand costs no extra pass over L.  n % 256 == 0,
+ *                    n >= 512 (gpvae_potrf_b3_supported).  A, info, flags as gpvae_potrf; with
+ *                    GPVAE_POTRF_NAN_ON_FAIL a failed matrix's planes are NaN on the diagonal blocks
+ *                    (every draw from them is NaN).  work: gpvae_potrf_b3_workspace_bytes().        */
+int gpvae_potrf_b3_supported(int64_t n);
+int64_t gpvae_potrf_b3_workspace_bytes(int64_t n, int batch);
+int gpvae_potrf_b3(void *stream, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                   int32_t *info, int flags, void *work, void *L3, int64_t ld3, int64_t plane,
+                   int64_t stride3);
 int gpvae_split_b3(void *stream, int64_t rows, int64_t cols, int batch, const void *X, int64_t ldx,
                    int64_t strideX, int lower, void *out3, int64_t ld3, int64_t plane,
                    int64_t stride3);

@@ -354,3 +354,40 @@ def test_b3_draw_full_size_c3():
     want = (E[rows].double() @ torch.tril(K).double().T + 0.05 * E2[rows].double()).cpu().numpy()
     e_b3, e_f32 = rel(Y[rows], want), rel(Yf[rows], want)
     assert e_b3 < 1e-5 and e_b3 < 2 * e_f32 + 1e-7, (e_b3, e_f32)
+
+
+def test_potrf_b3_factor_and_planes():
+    """gpvae_potrf_b3: the float32 factor equals gpvae_potrf's to LAPACK-level backward error, and the planes
+    it leaves are the factor bit for bit on and below the diagonal — and zero wherever the draw reads
+    above it: draws from them equal draws from split_b3(tril(L)).  Non-PD matrix in the batch: info."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(5)
+    assert ops.potrf_b3_supported(4096) and ops.potrf_b3_supported(512) and not ops.potrf_b3_supported(300) \
+        and not ops.potrf_b3_supported(256)
+    for n, batch in ((512, 3), (1280, 9)):
+        x = torch.tensor(rng.random((n, 2)), dtype=torch.float32, device=DEV)
+        ls = torch.linspace(0.05, 0.6, batch, device=DEV)
+        K = ops.gram_se(x, x, torch.ones(batch, device=DEV), ls, 1e-3).reshape(batch, n, n)
+        K[1, 300, 300] = -1.0  # not positive definite from column 301
+        A = K.clone()
+        junk = torch.full((batch, 3, n, n), 7.0, dtype=torch.bfloat16, device=DEV)  # planes start as garbage
+        info, L3 = ops.potrf_b3_(A, junk)
+        assert info.cpu().tolist() == [0, 301] + [0] * (batch - 2)
+        ref = K.clone()
+        assert torch.equal(ops.potrf_(ref, zero_upper=False, nan_on_fail=False), info)
+        for b in (0, 2, batch - 1):
+            L = torch.tril(A[b]).double()
+            Kb = K[b].double()
+            assert (torch.linalg.norm(L @ L.T - Kb) / torch.linalg.norm(Kb)).item() < 2e-6
+            # planes == factor bit for bit, except where a piece underflows bf16's normal range (entries < 1e-30)
+            dif = (torch.tril(L3[b].float().sum(0)) - torch.tril(A[b])).abs()
+            assert dif.max().item() < 1e-30 and torch.equal(dif > 0, (dif > 0) & (A[b].tril().abs() < 1e-28))
+            E3 = ops.randn_b3((256, n), DEV, seed=b, stream_id=2)
+            want = ops.draw_b3(ops.split_b3(A[b], lower=True), E3)
+            assert torch.equal(ops.draw_b3(L3[b], E3), want)
+            assert rel(A[b].tril(), ref[b].tril().cpu().numpy()) < 1e-6  # same factor as the plain entry point
+        # NaN-on-fail: every draw from a failed matrix's planes is NaN
+        A2 = K.clone()
+        info2, L32 = ops.potrf_b3_(A2, nan_on_fail=True)
+        assert torch.isnan(ops.draw_b3(L32[1], ops.randn_b3((256, n), DEV, seed=1))).all()
+        assert not torch.isnan(ops.draw_b3(L32[0], ops.randn_b3((256, n), DEV, seed=1))).any()

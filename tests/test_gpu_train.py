@@ -53,13 +53,13 @@ def test_step_engine_matches_oracle_train_steps(tdt, ndt, tol):
 
 
 def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
-    """Shapes that put the engine's draws on the bf16 matrix pipe (float32, n % 128 == 0, B % 256 == 0):
+    """Shapes that put the engine's factorisations and draws on the bf16 matrix pipe (float32, n % 256 == 0, B % 256 == 0):
     same float32 bar against oracle.train_step as the f32-MFMA engine, and the two engines agree."""
     from gp_vae_amd import ops, parallel
     from gp_vae_amd.gp import draw_hyper
     from gp_vae_amd.vae import StepEngine, SVIState
-    n, B, dims, lr, jit = 256, 256, (20, 12, 5), 1e-3, 1e-3
-    g = np.arange(0, 1, 1 / 16)
+    n, B, dims, lr, jit = 1024, 256, (20, 12, 5), 1e-3, 1e-3
+    g = np.arange(0, 1, 1 / 32)
     u, v = np.meshgrid(g, g)
     x = np.stack([u.ravel(), v.ravel()], 1)
     keys = [(5, i) for i in range(3)]
