@@ -141,6 +141,77 @@ __global__ __launch_bounds__(NTHREADS) void draw_batched_kernel(
   }
 }
 
+
+// ---- f3: hyper-prior samplers on the device ---------------------------------------------------------
+// (ls, var, sigma) of GP.sample / epoch_train (gp.py:171-176, vae.py:157-159) without a host round
+// trip: var ~ LogNormal(0, s_var), sigma ~ HalfNormal(s_sig), ls ~ InverseGamma(a, b) = b / Gamma(a)
+// or Beta(a, b) = Ga / (Ga + Gb) (the README's prior).  Gamma by Marsaglia & Tsang (2000) with the
+// a < 1 boost Gamma(a) = Gamma(a + 1) U^(1/a); every random word is Philox4x32-10 of a counter that
+// names (sample index, purpose, attempt), so sample i does not depend on how calls are batched.
+// All arithmetic in double (results are rounded to T at the end): the oracle restates it to ~1 ulp.
+struct HyperRng {
+  uint64_t seed, stream_id;
+  uint32_t idx;
+  // words of counter (idx, purpose << 24 | attempt, stream)
+  __device__ void words(uint32_t purpose, uint32_t attempt, uint32_t (&c)[4]) const {
+    c[0] = idx; c[1] = (purpose << 24) | attempt; c[2] = (uint32_t)stream_id; c[3] = (uint32_t)(stream_id >> 32);
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  }
+  __device__ static double unif(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+  // (normal, normal) from words 0, 1 (Box-Muller, as philox_normals4<double>)
+  __device__ static void normals(const uint32_t (&c)[4], double &z0, double &z1) {
+    const double rad = sqrt(-2.0 * log(unif(c[0])));
+    double sn, cs;
+    sincospi(2.0 * unif(c[1]), &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+  }
+  __device__ double gamma(double a, uint32_t purpose) const {
+    const double a1 = a < 1.0 ? a + 1.0 : a;
+    const double d = a1 - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    double g = d;  // (64 rejections in a row have probability < 1e-80: the mean stands in)
+    for (uint32_t k = 0; k < 64; ++k) {
+      uint32_t c[4];
+      words(purpose, k, c);
+      double x, unused;
+      normals(c, x, unused);
+      const double t = 1.0 + cc * x, v = t * t * t;
+      if (v > 0.0 && log(unif(c[2])) < 0.5 * x * x + d - d * v + d * log(v)) { g = d * v; break; }
+    }
+    if (a < 1.0) {
+      uint32_t c[4];
+      words(purpose + 1, 0, c);
+      g *= pow(unif(c[0]), 1.0 / a);
+    }
+    return g;
+  }
+};
+
+template <typename T>
+__global__ void hyper_sample_kernel(int64_t count, uint64_t seed, uint64_t stream_id, uint32_t first,
+                                    int ls_prior, double ls_a, double ls_b, double s_var, double s_sig,
+                                    T *ls, T *var, T *sigma) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  HyperRng r{seed, stream_id, first + (uint32_t)i};
+  uint32_t c[4];
+  r.words(0, 0, c);
+  double z0, z1;
+  HyperRng::normals(c, z0, z1);
+  if (var) var[i] = (T)exp(s_var * z0);
+  if (sigma) sigma[i] = (T)fabs(s_sig * z1);
+  if (ls) {
+    double v;
+    if (ls_prior == GPVAE_PRIOR_INVGAMMA) {
+      v = ls_b / r.gamma(ls_a, 1);
+    } else {
+      const double ga = r.gamma(ls_a, 1), gb = r.gamma(ls_b, 3);
+      v = ga / (ga + gb);
+    }
+    ls[i] = (T)v;
+  }
+}
+
 template <typename T>
 __global__ void randn_kernel(int64_t count, uint64_t seed, uint64_t stream_id, T *out) {
   const int64_t nq = (count + 3) / 4;
@@ -257,5 +328,27 @@ extern "C" int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed
     hipLaunchKernelGGL((randn_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, count,
                        seed, stream_id, (double *)out);
   GPVAE_CHECK_LAUNCH("gpvae_randn");
+  return 0;
+}
+
+extern "C" int gpvae_hyper_sample(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
+                                  int64_t first_index, int ls_prior, double ls_a, double ls_b,
+                                  double var_scale, double sigma_scale, void *ls, void *var, void *sigma) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_hyper_sample: bad dtype %d", dtype);
+  GPVAE_REQUIRE(count >= 0, 3, "gpvae_hyper_sample: count < 0");
+  GPVAE_REQUIRE(first_index >= 0 && first_index + count <= 0xffffffffLL, 6, "gpvae_hyper_sample: sample indices must fit 32 bits");
+  GPVAE_REQUIRE(ls_prior == GPVAE_PRIOR_INVGAMMA || ls_prior == GPVAE_PRIOR_BETA, 7, "gpvae_hyper_sample: unknown lengthscale prior %d", ls_prior);
+  GPVAE_REQUIRE(ls_a > 0 && ls_b > 0, 8, "gpvae_hyper_sample: prior parameters must be > 0");
+  GPVAE_REQUIRE(var_scale >= 0 && sigma_scale >= 0, 10, "gpvae_hyper_sample: scales must be >= 0");
+  if (count == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)cdiv(count, 64));
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((hyper_sample_kernel<float>), grid, dim3(64), 0, st, count, seed, stream_id, (uint32_t)first_index,
+                       ls_prior, ls_a, ls_b, var_scale, sigma_scale, (float *)ls, (float *)var, (float *)sigma);
+  else
+    hipLaunchKernelGGL((hyper_sample_kernel<double>), grid, dim3(64), 0, st, count, seed, stream_id, (uint32_t)first_index,
+                       ls_prior, ls_a, ls_b, var_scale, sigma_scale, (double *)ls, (double *)var, (double *)sigma);
+  GPVAE_CHECK_LAUNCH("gpvae_hyper_sample");
   return 0;
 }

@@ -237,6 +237,26 @@ def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=No
     return out
 
 
+PRIOR_INVGAMMA, PRIOR_BETA = 0, 1
+
+
+def hyper_sample(count, dtype=torch.float32, device="cuda", seed=0, stream_id=0, first_index=0,
+                 ls_prior=PRIOR_INVGAMMA, ls_a=1.0, ls_b=0.1, var_scale=0.1, sigma_scale=0.1, out=None):
+    """(ls, var, sigma) [count] from the hyper-priors on the device (vae.py:157-159 by default:
+    InverseGamma(1, .1), LogNormal(0, .1), HalfNormal(.1)).  out: optional [3, >=count] tensor whose rows
+    var | ls | sigma (StepEngine's layout) are filled."""
+    if out is None:
+        out = torch.empty((3, count), dtype=dtype, device=device)
+    _dev(out)
+    if out.dim() != 2 or out.shape[0] != 3 or out.shape[1] < count or (out.shape[1] > 1 and out.stride(1) != 1):
+        raise GpvaeError("hyper_sample: out must be [3, >= count] with contiguous rows")
+    check(_lib.load().gpvae_hyper_sample(_stream(), _dt(out), int(count), int(seed), int(stream_id), int(first_index),
+                                         int(ls_prior), float(ls_a), float(ls_b), float(var_scale),
+                                         float(sigma_scale), _p(out[1]), _p(out[0]), _p(out[2])),
+          "gpvae_hyper_sample")
+    return out[1, :count], out[0, :count], out[2, :count]
+
+
 # ---- bf16 x 3 (b3) operands: three bf16 planes that sum to the float exactly --------------------------
 def split_b3(X, lower=False, out=None):
     """float32 X [rows, cols] or [batch, rows, cols] -> bf16 planes [3, rows, cols] / [batch, 3, rows, cols]

@@ -215,6 +215,8 @@ class StepEngine():
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
                  hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2, mfma="auto"):
+        if isinstance(hyper_sampler, str) and hyper_sampler != "device":
+            raise ValueError("hyper_sampler: a callable rng -> (ls, var, sigma) or 'device'")
         if kernel is not exp_kernel2:
             # the engine calls gpvae_gram_se itself: another kernel would silently train on SE
             raise NotImplementedError("StepEngine builds its Gram matrices with gpvae_gram_se (exp_kernel2); "
@@ -285,20 +287,35 @@ class StepEngine():
     # -- stage A: the factors of one group of steps (own stream) ---------------------------------------
     def _issue_factors(self, keys, slot):
         g = len(keys)
-        pin = self.hyper_pin[slot]
-        self.ev_copied[slot].synchronize()  # the staging block's previous upload has left the host
-        for i, key in enumerate(keys):
-            ls, var, sigma = self.hyper_sampler(step_rng(self.seed, self.rank, key))
-            pin[0, i], pin[1, i], pin[2, i] = float(var), float(ls), float(sigma)
-        for i in range(g, self.G):  # unused slots of a short last group: harmless values
-            pin[0, i], pin[1, i], pin[2, i] = 1.0, 1.0, 0.0
+        device_hyper = isinstance(self.hyper_sampler, str)
+        if not device_hyper:
+            pin = self.hyper_pin[slot]
+            self.ev_copied[slot].synchronize()  # the staging block's previous upload has left the host
+            for i, key in enumerate(keys):
+                ls, var, sigma = self.hyper_sampler(step_rng(self.seed, self.rank, key))
+                pin[0, i], pin[1, i], pin[2, i] = float(var), float(ls), float(sigma)
+            for i in range(g, self.G):  # unused slots of a short last group: harmless values
+                pin[0, i], pin[1, i], pin[2, i] = 1.0, 1.0, 0.0
         stream = self.s_gp if self.overlap else torch.cuda.current_stream()
         if self.overlap:
             stream.wait_event(self.ev_free[slot])  # the draws that read this slot's factors are done
         with torch.cuda.stream(stream):
             hd = self.hyper_dev[slot]
-            hd.copy_(pin, non_blocking=True)
-            self.ev_copied[slot].record(stream)
+            if device_hyper:
+                # hyper_sampler="device": (ls, var, sigma) of step (k, i) is sample i of the Philox stream
+                # of (rank, k) — drawn by gpvae_hyper_sample on the factor stream, no host round trip
+                runs, lo = [], 0
+                for i in range(1, g + 1):  # runs of consecutive steps of one epoch key: one launch each
+                    if i == g or keys[i][0] != keys[lo][0] or keys[i][-1] != keys[i - 1][-1] + 1:
+                        runs.append((lo, i))
+                        lo = i
+                for lo, hi in runs:
+                    cnt = self.G - lo if hi == g else hi - lo  # the tail also fills a short group's unused slots
+                    ops.hyper_sample(cnt, seed=self.seed, stream_id=philox_stream_id(self.rank, (keys[lo][0], 0), 5),
+                                     first_index=keys[lo][-1], out=hd[:, lo:lo + cnt])
+            else:
+                hd.copy_(pin, non_blocking=True)
+                self.ev_copied[slot].record(stream)
             K = self.Kbuf[slot]
             lib = _lib.load()
             check(lib.gpvae_gram_se(_stream(), _dt(K), self.d, self.n, self.n, _p(self.x),

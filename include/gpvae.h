@@ -157,6 +157,19 @@ int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3, int64_t l
                   const void *E3, int64_t lde, int64_t planeE, const void *E2, int64_t lde2,
                   const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy);
 
+/* ---- f3: hyper-prior samplers on the device -------------------------------------------------------
+ * Replaces the three numpyro.sample draws of the training loop and of GP.sample
+ * (src/model/vae.py:157-159, gp.py:171-176): for i in [0, count)
+ *   var[i] ~ LogNormal(0, var_scale), sigma[i] ~ HalfNormal(sigma_scale),
+ *   ls[i] ~ InverseGamma(ls_a, ls_b) (GPVAE_PRIOR_INVGAMMA; the code's prior is (1, 0.1), the kriging
+ *           model's (4, 1): inference.py:372) or Beta(ls_a, ls_b) (GPVAE_PRIOR_BETA; README.md:17).
+ * Sample i depends only on (seed, stream_id, first_index + i): batching does not change the draws.
+ * Any of ls / var / sigma may be NULL.  Stands in for JAX's threefry stream like gpvae_randn.       */
+enum { GPVAE_PRIOR_INVGAMMA = 0, GPVAE_PRIOR_BETA = 1 };
+int gpvae_hyper_sample(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
+                       int64_t first_index, int ls_prior, double ls_a, double ls_b, double var_scale,
+                       double sigma_scale, void *ls, void *var, void *sigma);
+
 /* ---- a9: kriging prediction ---------------------------------------------------------------------
  * Replaces GPInference.gp_prediction (src/model/inference.py:427-460), literal quirks kept:
  *   A = k_xx + jitter*I + sigma*I   (sigma, not sigma^2: inference.py:450)

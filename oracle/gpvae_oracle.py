@@ -359,6 +359,57 @@ def draw_hyper(rng):
     return float(ls), var, float(sigma)
 
 
+def _hyper_words(idx, purpose, attempt, seed, stream_id):
+    ctr = np.array([[idx & 0xFFFFFFFF, ((purpose << 24) | attempt) & 0xFFFFFFFF, stream_id & 0xFFFFFFFF,
+                     (stream_id >> 32) & 0xFFFFFFFF]], dtype=np.uint32)
+    return [int(w) for w in philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))[0]]
+
+
+def _unif(w):
+    return (float(w) + 0.5) / 4294967296.0
+
+
+def _philox_gamma(a, idx, purpose, seed, stream_id):
+    """Marsaglia & Tsang (2000) on Philox words, as gpvae_hyper_sample's device sampler does it."""
+    import math
+    a1 = a + 1.0 if a < 1.0 else a
+    d = a1 - 1.0 / 3.0
+    cc = 1.0 / math.sqrt(9.0 * d)
+    g = d
+    for k in range(64):
+        c = _hyper_words(idx, purpose, k, seed, stream_id)
+        x = math.sqrt(-2.0 * math.log(_unif(c[0]))) * math.cos(2.0 * math.pi * _unif(c[1]))
+        t = 1.0 + cc * x
+        v = t * t * t
+        if v > 0.0 and math.log(_unif(c[2])) < 0.5 * x * x + d - d * v + d * math.log(v):
+            g = d * v
+            break
+    if a < 1.0:
+        g *= _unif(_hyper_words(idx, purpose + 1, 0, seed, stream_id)[0]) ** (1.0 / a)
+    return g
+
+
+def hyper_sample(count, seed=0, stream_id=0, first_index=0, ls_prior="invgamma", ls_a=1.0, ls_b=0.1,
+                 var_scale=0.1, sigma_scale=0.1):
+    """(ls, var, sigma) [count] (float64): the hyper-priors of gp.py:171-176 / vae.py:157-159 drawn from
+    counter-based Philox words — var ~ LogNormal(0, var_scale), sigma ~ HalfNormal(sigma_scale),
+    ls ~ InverseGamma(a, b) = b / Gamma(a) or Beta(a, b) = Ga / (Ga + Gb) (README.md:17)."""
+    import math
+    ls, var, sig = np.empty(count), np.empty(count), np.empty(count)
+    for i in range(count):
+        idx = first_index + i
+        c = _hyper_words(idx, 0, 0, seed, stream_id)
+        rad = math.sqrt(-2.0 * math.log(_unif(c[0])))
+        var[i] = math.exp(var_scale * rad * math.cos(2.0 * math.pi * _unif(c[1])))
+        sig[i] = abs(sigma_scale * rad * math.sin(2.0 * math.pi * _unif(c[1])))
+        if ls_prior == "invgamma":
+            ls[i] = ls_b / _philox_gamma(ls_a, idx, 1, seed, stream_id)
+        else:
+            ga, gb = _philox_gamma(ls_a, idx, 1, seed, stream_id), _philox_gamma(ls_b, idx, 3, seed, stream_id)
+            ls[i] = ga / (ga + gb)
+    return ls, var, sig
+
+
 def train_step(p, m, v, t, x, hyper, eps, eps2, eps_z, lr, jitter, obs_sigma=0.1):
     """One body_fn of VAE.epoch_train (vae.py:150-167) with every random input explicit."""
     ls, var, sigma = hyper

@@ -391,3 +391,36 @@ def test_potrf_b3_factor_and_planes():
         info2, L32 = ops.potrf_b3_(A2, nan_on_fail=True)
         assert torch.isnan(ops.draw_b3(L32[1], ops.randn_b3((256, n), DEV, seed=1))).all()
         assert not torch.isnan(ops.draw_b3(L32[0], ops.randn_b3((256, n), DEV, seed=1))).any()
+
+
+@pytest.mark.parametrize("tdt,tol", [(torch.float64, 1e-12), (torch.float32, 2e-7)])
+def test_device_hyper_prior_samplers(tdt, tol):
+    """gpvae_hyper_sample against the oracle's restatement (same Philox words, same Marsaglia-Tsang
+    accept/reject): InverseGamma(1, .1) / LogNormal / HalfNormal of vae.py:157-159, the kriging model's
+    InverseGamma(4, 1), the README's Beta(.1, 2); batching independence; and the engine trained with
+    hyper_sampler='device' equals the engine fed the oracle's draws from the host."""
+    from gp_vae_amd import ops, parallel
+    from gp_vae_amd.vae import StepEngine, SVIState, init_params
+    for kw_d, kw_o in (({}, {}), ({"ls_a": 4.0, "ls_b": 1.0}, {"ls_a": 4.0, "ls_b": 1.0}),
+                       ({"ls_prior": ops.PRIOR_BETA, "ls_a": 0.1, "ls_b": 2.0}, {"ls_prior": "beta", "ls_a": 0.1, "ls_b": 2.0})):
+        ls, var, sig = ops.hyper_sample(300, tdt, DEV, seed=77, stream_id=5, first_index=40, **kw_d)
+        lo, vo, so = orc.hyper_sample(300, seed=77, stream_id=5, first_index=40, **kw_o)
+        assert rel(ls, lo) < tol and rel(var, vo) < tol and rel(sig, so) < tol, kw_d
+    a = ops.hyper_sample(8, tdt, DEV, seed=1, stream_id=2, first_index=5)
+    b = ops.hyper_sample(20, tdt, DEV, seed=1, stream_id=2, first_index=0)
+    assert all(torch.equal(u, v[5:13]) for u, v in zip(a, b))
+    if tdt == torch.float64:
+        n, B, dims = 96, 40, (12, 9, 4)
+        x = np.arange(0, 1, 1 / n)
+        keys = [(2, i) for i in range(5)] + [(3, 0), (3, 1)]  # two epoch keys: two sampler launches in a group
+        e1 = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=tdt, seed=3, group=4, hyper_sampler="device")
+
+        def from_oracle(rng):  # host sampler that replays the device stream: key rides in through a closure
+            k = from_oracle.keys.pop(0)
+            l, v, s = orc.hyper_sample(1, seed=3, stream_id=parallel.philox_stream_id(0, (k[0], 0), 5), first_index=k[-1])
+            return l[0], v[0], s[0]
+        from_oracle.keys = list(keys)
+        e2 = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=tdt, seed=3, group=4, hyper_sampler=from_oracle)
+        s1, s2 = (SVIState(init_params(n, *dims, 7, tdt, DEV) * 5) for _ in range(2))
+        l1, l2 = e1.run(keys, s1).item(), e2.run(keys, s2).item()
+        assert abs(l1 - l2) < 1e-9 * abs(l2) and rel(s1.params, s2.params.cpu().numpy()) < 1e-9

@@ -242,3 +242,18 @@ def test_mvn_logp_matches_scipy_and_finite_differences():
         e = np.zeros(n); e[3] = h
         fd_f = (orc.mvn_logp(x, f + e, var, ls, jit) - orc.mvn_logp(x, f - e, var, ls, jit)) / (2 * h)
         assert abs(gf[3] - fd_f) < 1e-4 * max(1, abs(fd_f))
+
+
+def test_philox_hyper_prior_samplers():
+    """The counter-based hyper-prior samplers (restated for gpvae_hyper_sample): moments of
+    InverseGamma / LogNormal / HalfNormal / Beta, batching independence, determinism."""
+    ls, var, sig = orc.hyper_sample(6000, seed=3, stream_id=9)
+    assert abs(np.median(ls) - 0.1 / np.log(2)) < 0.01                      # InverseGamma(1, .1)
+    assert abs(np.std(np.log(var)) - 0.1) < 0.005 and abs(np.mean(np.log(var))) < 0.005
+    assert abs(np.mean(sig) - 0.1 * np.sqrt(2 / np.pi)) < 0.003 and (sig >= 0).all()
+    lb, _, _ = orc.hyper_sample(6000, seed=3, stream_id=9, ls_prior="beta", ls_a=0.1, ls_b=2.0)
+    assert abs(lb.mean() - 0.1 / 2.1) < 0.006 and ((lb >= 0) & (lb <= 1)).all()  # Beta(.1, 2): mean a/(a+b)
+    l4, _, _ = orc.hyper_sample(6000, seed=4, ls_a=4.0, ls_b=1.0)
+    assert abs(l4.mean() - 1 / 3.0) < 0.01                                   # InverseGamma(4, 1): b/(a-1)
+    a = orc.hyper_sample(10, seed=3, stream_id=9, first_index=100)
+    assert all(np.array_equal(u, v[100:110]) for u, v in zip(a, orc.hyper_sample(110, seed=3, stream_id=9)))
