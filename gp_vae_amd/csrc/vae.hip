@@ -832,6 +832,94 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
   return 0;
 }
 
+
+// ---- a11 in one launch: potential of VAEInference.regression and its gradient ---------------------------
+// (inference.py:243-254 in NumPyro's unconstrained space: q = (z [zd], u = log noise))
+//   U = -[ log N(y_obs; f[obs], sigma) + log N(z; 0, I) + log HalfNormal(sigma; s0) + u ],  sigma = e^u
+// The likelihood touches the decoder's output only at the n_obs observed locations, so the output layer
+// is evaluated (and differentiated) on the GATHERED columns V3[:, obs], c3[obs] — n_obs * h0 work per
+// chain instead of n * h0 — and everything of a block of RB chains stays in LDS: one launch instead of
+// decoder forward + ~12 elementwise / reduction / scatter launches + decoder VJP.
+template <typename T, int RB>
+__global__ __launch_bounds__(NTHREADS) void vae_potential_kernel(
+    int64_t chains, int64_t n, int h0, int h1, int z, int n_obs, const T *dec_params, const T *q,
+    int64_t ldq, const T *y_obs, const int64_t *obs_idx, T s0p, T *U, T *dU, int64_t lddu) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *w = reinterpret_cast<T *>(smem_raw);
+  const int nmid = z * h1 + h1 + h1 * h0 + h0;
+  T *V1 = w, *c1 = V1 + z * h1, *V2 = c1 + h1, *c2 = V2 + h1 * h0;
+  T *V3g = w + nmid;                 // [h0][n_obs]
+  T *c3g = V3g + h0 * n_obs;         // [n_obs]
+  T *yo = c3g + n_obs;               // [n_obs]
+  T *Zb = yo + n_obs;                // [RB][z]
+  T *D1 = Zb + RB * z;               // [RB][h1]
+  T *D2 = D1 + RB * h1;              // [RB][h0]
+  T *R = D2 + RB * h0;               // [RB][n_obs]   residual, then dF at the observed columns
+  T *G2 = R + RB * n_obs;            // [RB][h0]
+  T *G1 = G2 + RB * h0;              // [RB][h1]
+  T *dz = G1 + RB * h1;              // [RB][z]
+  T *su = dz + RB * z;               // [RB] u, then 1/sigma^2
+  const int tid = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * RB;
+  const int rows = (int)((chains - c0 < RB) ? chains - c0 : RB);
+  const T *V3 = dec_params + nmid, *c3 = V3 + (int64_t)h0 * n;
+  for (int i = tid; i < nmid; i += NTHREADS) w[i] = dec_params[i];
+  for (int i = tid; i < h0 * n_obs; i += NTHREADS) V3g[i] = V3[(int64_t)(i / n_obs) * n + obs_idx[i % n_obs]];
+  for (int i = tid; i < n_obs; i += NTHREADS) {
+    c3g[i] = c3[obs_idx[i]];
+    yo[i] = y_obs[i];
+  }
+  for (int i = tid; i < RB * z; i += NTHREADS) Zb[i] = (i / z < rows) ? q[(c0 + i / z) * ldq + i % z] : T(0);
+  if (tid < RB) su[tid] = (tid < rows) ? q[(c0 + tid) * ldq + z] : T(0);
+  __syncthreads();
+  dense_fwd<T, RB>(Zb, z, V1, c1, h1, D1, tid);
+  __syncthreads();
+  for (int i = tid; i < RB * h1; i += NTHREADS) D1[i] = D1[i] > T(0) ? D1[i] : T(0);
+  __syncthreads();
+  dense_fwd<T, RB>(D1, h1, V2, c2, h0, D2, tid);
+  __syncthreads();
+  for (int i = tid; i < RB * h0; i += NTHREADS) D2[i] = D2[i] > T(0) ? D2[i] : T(0);
+  __syncthreads();
+  dense_fwd<T, RB>(D2, h0, V3g, c3g, n_obs, R, tid);  // f at the observed locations
+  __syncthreads();
+  for (int i = tid; i < RB * n_obs; i += NTHREADS) R[i] -= yo[i % n_obs];
+  __syncthreads();
+  if (tid < rows) {  // one lane per chain: the scalar part of the potential
+    const int r = tid;
+    const T u = su[r], sigma = dexp<T>(u), iv = T(1) / (sigma * sigma);
+    T sq = T(0), zz = T(0);
+    for (int j = 0; j < n_obs; ++j) sq += R[r * n_obs + j] * R[r * n_obs + j];
+    for (int j = 0; j < z; ++j) zz += Zb[r * z + j] * Zb[r * z + j];
+    const T hl2p = T(0.9189385332046727), rs = sigma / s0p;
+    const T log_lik = T(-0.5) * sq * iv - (T)n_obs * (u + hl2p);
+    const T log_pz = T(-0.5) * zz - (T)z * hl2p;
+    const T log_ps = T(0.6931471805599453) - hl2p - (T)log((double)s0p) - T(0.5) * rs * rs + u;
+    U[c0 + r] = -(log_lik + log_pz + log_ps);
+    dU[(c0 + r) * lddu + z] = rs * rs - T(1) + (T)n_obs - sq * iv;
+    su[r] = iv;
+  }
+  __syncthreads();
+  for (int i = tid; i < RB * n_obs; i += NTHREADS) R[i] *= su[i / n_obs];  // dF[obs] = r / sigma^2
+  __syncthreads();
+  dense_bwd_in<T, RB>(R, n_obs, V3g, h0, G2, tid);
+  __syncthreads();
+  for (int i = tid; i < RB * h0; i += NTHREADS) G2[i] = D2[i] > T(0) ? G2[i] : T(0);
+  __syncthreads();
+  dense_bwd_in<T, RB>(G2, h0, V2, h1, G1, tid);
+  __syncthreads();
+  for (int i = tid; i < RB * h1; i += NTHREADS) G1[i] = D1[i] > T(0) ? G1[i] : T(0);
+  __syncthreads();
+  dense_bwd_in<T, RB>(G1, h1, V1, z, dz, tid);
+  __syncthreads();
+  for (int i = tid; i < RB * z; i += NTHREADS)
+    if (i / z < rows) dU[(c0 + i / z) * lddu + i % z] = Zb[i] + dz[i];
+}
+
+static inline int64_t vae_potential_lds(int64_t es, int rb, int h0, int h1, int z, int64_t n_obs) {
+  return es * ((int64_t)z * h1 + h1 + (int64_t)h1 * h0 + h0 + (int64_t)h0 * n_obs + 2 * n_obs +
+               (int64_t)rb * (2 * z + 2 * h1 + 2 * h0 + n_obs + 1));
+}
+
 // sd = exp(log sd) in place; Z = MU + sd * eps when eps and Z are given (the guide's sample, vae.py:135)
 template <typename T>
 __global__ void exp_reparam_kernel(int64_t count, const T *__restrict__ MU, T *SD,
@@ -990,6 +1078,47 @@ extern "C" int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_
   return dtype == GPVAE_F32
              ? run_decoder<float>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work)
              : run_decoder<double>(st, true, chains, n, h0, h1, z, dec_params, Z, dF, dZ, work);
+}
+
+extern "C" int gpvae_vae_potential_supported(int dtype, int h0, int h1, int z, int64_t n_obs) {
+  if (dtype != GPVAE_F32 && dtype != GPVAE_F64) return 0;
+  if (h0 < 1 || h1 < 1 || z < 1 || n_obs < 1) return 0;
+  return vae_potential_lds(dtype == GPVAE_F64 ? 8 : 4, 4, h0, h1, z, n_obs) <= 64 * 1024;
+}
+
+extern "C" int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
+                                   const void *dec_params, const void *q, int64_t ldq, const void *y_obs,
+                                   const int64_t *obs_idx, int64_t n_obs, double noise_scale, void *U,
+                                   void *dU, int64_t lddu) {
+  if (int rc = check_dims("gpvae_vae_potential", dtype, chains, n, h0, h1, z)) return rc;
+  GPVAE_REQUIRE(n_obs >= 1 && n_obs <= n, 13, "gpvae_vae_potential: n_obs out of range [1, n]");
+  GPVAE_REQUIRE(gpvae_vae_potential_supported(dtype, h0, h1, z, n_obs), 5,
+                "gpvae_vae_potential: decoder head + gathered output columns exceed 64 KB of LDS "
+                "(gpvae_vae_potential_supported); use gpvae_decoder_fwd / gpvae_decoder_vjp");
+  if (chains == 0) return 0;
+  GPVAE_REQUIRE(dec_params && q && y_obs && obs_idx && U && dU, 8, "gpvae_vae_potential: NULL pointer");
+  GPVAE_REQUIRE(ldq >= z + 1, 10, "gpvae_vae_potential: ldq < z + 1");
+  GPVAE_REQUIRE(lddu >= z + 1, 17, "gpvae_vae_potential: lddu < z + 1");
+  GPVAE_REQUIRE(noise_scale > 0, 14, "gpvae_vae_potential: noise_scale must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  int rb = 4;
+  for (int c : {16, 8})
+    if (vae_potential_lds(es, c, h0, h1, z, n_obs) <= 64 * 1024) { rb = c; break; }
+  const size_t shm = (size_t)vae_potential_lds(es, rb, h0, h1, z, n_obs);
+  const unsigned nblk = (unsigned)cdiv(chains, rb);
+#define GPVAE_POT_LAUNCH(T, RBV)                                                                          \
+  hipLaunchKernelGGL((vae_potential_kernel<T, RBV>), dim3(nblk), dim3(NTHREADS), shm, st, chains, n, h0, h1, \
+                     z, (int)n_obs, (const T *)dec_params, (const T *)q, ldq, (const T *)y_obs, obs_idx,   \
+                     (T)noise_scale, (T *)U, (T *)dU, lddu)
+  if (dtype == GPVAE_F32) {
+    if (rb == 16) GPVAE_POT_LAUNCH(float, 16); else if (rb == 8) GPVAE_POT_LAUNCH(float, 8); else GPVAE_POT_LAUNCH(float, 4);
+  } else {
+    if (rb == 16) GPVAE_POT_LAUNCH(double, 16); else if (rb == 8) GPVAE_POT_LAUNCH(double, 8); else GPVAE_POT_LAUNCH(double, 4);
+  }
+#undef GPVAE_POT_LAUNCH
+  GPVAE_CHECK_LAUNCH("gpvae_vae_potential");
+  return 0;
 }
 
 // ---- the one entry point that takes no workspace and allocates nothing ------------------------------

@@ -344,7 +344,14 @@ class VAEInference(Inference):
         q0 = torch.zeros(zd + 1, dtype=dt, device=dev)
         q0[zd] = math.log(0.0674)  # median of HalfNormal(0.1)
 
+        y_obs = y_obs.contiguous()
+        idx = idx.contiguous()
+        fused = ops.vae_potential_supported(dt, self.h0, self.h1, zd, idx.numel())
+
         def fn(q):
+            if fused:  # one launch per evaluation (gpvae_vae_potential)
+                return ops.vae_potential(self.dec_flat, q if q.stride(1) == 1 else q.contiguous(), y_obs, idx,
+                                         self.n_out, self.h0, self.h1)
             U, dz, du = self._potential(q[:, :zd], q[:, zd], y_obs, idx)
             return U, torch.cat([dz, du[:, None]], 1)
 
@@ -376,6 +383,12 @@ class VAEInference(Inference):
                y[obs] ~ Normal(decoder(z)[obs], sigma).
         Returns (U [chains], dU/dz [chains, z_dim], dU/dlog_sigma [chains]).  The decoder forward and
         its vector-Jacobian product are the HIP kernels; the O(chains * n_obs) tail is glue."""
+        zz = _as_device(z, self.dtype).reshape(-1, self.z_dim)
+        if ops.vae_potential_supported(self.dtype, self.h0, self.h1, self.z_dim, self.obs_idx.numel()):
+            q = torch.cat([zz, _as_device(log_sigma, self.dtype).reshape(-1, 1)], 1)
+            U, dU = ops.vae_potential(self.dec_flat, q, self.y[self.obs_idx].contiguous(), self.obs_idx.contiguous(),
+                                      self.n_out, self.h0, self.h1)
+            return U, dU[:, :self.z_dim], dU[:, self.z_dim]
         return self._potential(z, log_sigma, self.y[self.obs_idx], self.obs_idx)
 
     def _potential(self, z, log_sigma, y_obs, obs_idx):

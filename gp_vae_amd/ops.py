@@ -518,6 +518,25 @@ def decoder_vjp(dec_params, Z, dF, h0, h1):
     return dZ
 
 
+def vae_potential_supported(dtype, h0, h1, z, n_obs):
+    return bool(_lib.load().gpvae_vae_potential_supported(_DT[dtype], h0, h1, z, int(n_obs)))
+
+
+def vae_potential(dec_params, q, y_obs, obs_idx, n, h0, h1, noise_scale=0.1):
+    """(U [chains], dU/dq [chains, z+1]) of VAEInference.regression for q = (z, log noise) rows: one launch
+    (gpvae_vae_potential).  obs_idx: int64 device tensor."""
+    _dev(dec_params, q, y_obs, obs_idx)
+    if q.stride(1) != 1 or obs_idx.dtype != torch.long or not obs_idx.is_contiguous() or not y_obs.is_contiguous():
+        raise GpvaeError("vae_potential: q needs unit column stride; obs_idx int64 contiguous; y_obs contiguous")
+    chains, z = q.shape[0], q.shape[1] - 1
+    U = torch.empty(chains, dtype=q.dtype, device=q.device)
+    dU = torch.empty((chains, z + 1), dtype=q.dtype, device=q.device)
+    check(_lib.load().gpvae_vae_potential(_stream(), _dt(q), chains, n, h0, h1, z, _p(dec_params), _p(q), q.stride(0),
+                                          _p(y_obs), _p(obs_idx), obs_idx.numel(), float(noise_scale), _p(U), _p(dU),
+                                          dU.stride(0)), "gpvae_vae_potential")
+    return U, dU
+
+
 def decoder_vjp_static(dec_params, Z, dF, h0, h1, out=None):
     """decoder_vjp through gpvae_decoder_vjp_static: no workspace, no allocation inside the library
     (its scratch is a 4 MiB static device array per GPU; calls that overlap on one GPU race).  Pass

@@ -258,6 +258,21 @@ int gpvae_decoder_fwd(void *stream, int dtype, int64_t chains, int64_t n, int h0
 int gpvae_decoder_vjp(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
                       const void *dec_params, const void *Z, const void *dF, void *dZ, void *work);
 
+/* ---- a11 in one launch: potential energy of VAEInference.regression and its gradient ------------------
+ * Replaces what NUTS evaluates per leapfrog step for src/model/inference.py:243-254 (sites noise ~
+ * HalfNormal(noise_scale), z ~ N(0, I), y[obs] ~ Normal(decoder(z)[obs], noise)) in NumPyro's
+ * unconstrained space, for a batch of chains: q [chains, ldq] = (z [z_dim], log noise),
+ *   U[c] = potential energy,  dU [chains, lddu] = dU/dq.
+ * The likelihood reads the decoder's output only at obs_idx (int64 [n_obs], device), so the output
+ * layer is evaluated on the gathered columns: n_obs*h0 work per chain, everything in LDS, one launch.
+ * For decoders whose head fits LDS (gpvae_vae_potential_supported; the reference's 10-30-35-300 and
+ * 15-30-50-625 do); otherwise compose gpvae_decoder_fwd / gpvae_decoder_vjp.                          */
+int gpvae_vae_potential_supported(int dtype, int h0, int h1, int z, int64_t n_obs);
+int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1, int z,
+                        const void *dec_params, const void *q, int64_t ldq, const void *y_obs,
+                        const int64_t *obs_idx, int64_t n_obs, double noise_scale, void *U, void *dU,
+                        int64_t lddu);
+
 /* ---- the same VJP with no workspace argument and no allocation ------------------------------------
  * No counterpart in the reference.  For callers that cannot allocate or carry a workspace: code
  * under HIP graph capture, tight MCMC / serving loops, harnesses that forbid hipMalloc.  Same kernels
