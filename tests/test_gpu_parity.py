@@ -394,6 +394,58 @@ def test_kriging_mid_size_f64(ops):
     assert np.abs(var_out.cpu().numpy() - np.maximum(v_ref, 0)).max() < 1e-9
 
 
+def test_kriging_c4_full_size_properties(ops):
+    """C4 at full size (192x192 grid, 32768 observations, 4096 test points, f64): an 8 GiB factor in place,
+    buffer extents beyond 4 GiB and row offsets beyond 2^31 bytes (TileIO::usable / LoaderKC::fast_end
+    guards).  The oracle's LU inverse of this size is out of reach, so: info == 0; backward error of the
+    factor on sampled rows (L L^T)[rows] vs K[rows]; predictive variance >= 0 and <= prior variance;
+    the mean recovers the noise-free surface to the noise level; the sample uses the given normals."""
+    g = np.arange(192) / 192.0
+    u, v = np.meshgrid(g, g)
+    x = np.stack([u.ravel(), v.ravel()], 1)
+    rng = np.random.default_rng(0)
+    obs = np.sort(rng.permutation(x.shape[0])[:32768])
+    mask = np.ones(x.shape[0], bool); mask[obs] = False
+    surf = lambda p: np.sin(3 * np.pi * p[:, 0]) + 0.3 * np.cos(9 * np.pi * p[:, 1]) + 0.5 * np.sin(7 * np.pi * (p[:, 0] + p[:, 1]))
+    y = surf(x) + 0.05 * rng.standard_normal(x.shape[0])
+    xt = torch.tensor(x, dtype=torch.float64, device=DEV)
+    x_obs = xt[torch.tensor(obs, device=DEV)].contiguous()
+    x_test = xt[torch.tensor(np.nonzero(mask)[0], device=DEV)].contiguous()
+    n_obs = x_obs.shape[0]
+    # the factor alone: A = k_xx + (jitter + sigma) I, in place
+    A = ops.gram_se(x_obs, x_obs, 1.0, 0.2, 1e-5)
+    A.diagonal().add_(0.05)
+    assert int(ops.potrf_(A).item()) == 0  # upper triangle cleared: A is L
+    rows = torch.tensor(np.sort(rng.integers(0, n_obs, 24)), device=DEV)
+    Krows = ops.gram_se(x_obs[rows].contiguous(), x_obs, 1.0, 0.2, 0.0)
+    Krows[torch.arange(24, device=DEV), rows] += 1e-5 + 0.05
+    LLt = A[rows] @ A.T
+    assert (torch.linalg.norm(LLt - Krows) / torch.linalg.norm(Krows)).item() < 1e-13
+    del A, LLt
+    xi = ops.randn((x_test.shape[0],), torch.float64, DEV, seed=3)
+    mean, samp, var_out, info = ops.krig_predict(x_obs, x_test, torch.tensor(y[obs], dtype=torch.float64, device=DEV),
+                                                 1.0, 0.2, 0.05, 1e-5, xi)
+    assert int(info.item()) == 0
+    vo = var_out.cpu().numpy()
+    assert vo.min() >= 0.0 and vo.max() <= 1.0 + 1e-5 + 1e-12
+    # (ls = 0.2 smooths the 7-9 pi features: 0.351, the value round 1 measured; the zero predictor gives 0.93)
+    assert np.sqrt(np.mean((mean.cpu().numpy() - surf(x[mask])) ** 2)) < 0.4
+    assert rel(samp, (mean + torch.sqrt(var_out) * xi).cpu().numpy()) < 1e-14
+    # a closed-form answer at full size: for y = sum_j c_j A[:, j] (columns of A = k_xx + (jitter + sigma) I)
+    # A^-1 y = sum_j c_j e_j, so the kriging mean must be sum_j c_j k(x_test, x_obs[j]) exactly
+    cols = [123, 17000, 32767]
+    coef = [1.0, -2.5, 0.7]
+    yc = torch.zeros(n_obs, dtype=torch.float64, device=DEV)
+    want = torch.zeros(x_test.shape[0], dtype=torch.float64, device=DEV)
+    for j, c in zip(cols, coef):
+        col = ops.gram_se(x_obs, x_obs[j:j + 1].contiguous(), 1.0, 0.2, 0.0).reshape(-1)
+        col[j] += 1e-5 + 0.05
+        yc += c * col
+        want += c * ops.gram_se(x_test, x_obs[j:j + 1].contiguous(), 1.0, 0.2, 0.0).reshape(-1)
+    mean_c, _, _, info_c = ops.krig_predict(x_obs, x_test, yc, 1.0, 0.2, 0.05, 1e-5)
+    assert int(info_c.item()) == 0 and rel(mean_c, want.cpu().numpy()) < 1e-8, rel(mean_c, want.cpu().numpy())
+
+
 def test_gpinference_surface(ops, golden):
     from gp_vae_amd.gp import exp_kernel2
     from gp_vae_amd.inference import GPInference
