@@ -52,6 +52,8 @@ SIGNATURES = {
     "gpvae_mvn_workspace_bytes": (_i64, [_i, _i64, _i]),
     "gpvae_mvn_logp": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp,
                             _vp]),
+    "gpvae_gp_potential_workspace_bytes": (_i64, [_i, _i64, _i]),
+    "gpvae_gp_potential": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _i64, _vp, _vp]),
     "gpvae_vae_param_count": (_i64, [_i64, _i, _i, _i]),
     "gpvae_vae_workspace_bytes": (_i64, [_i, _i64, _i64, _i, _i, _i]),
     "gpvae_vae_elbo": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _d, _vp, _vp,

@@ -112,19 +112,16 @@ struct PipeB3 {
     }
   }
   template <int S> __device__ __forceinline__ void mma_sub() {
+    // piece products smallest first; consecutive MFMAs go to DIFFERENT accumulators (a dependent
+    // back-to-back pair on one accumulator would wait for the first one's last pass)
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-    for (int fm = 0; fm < WFM; ++fm)
+    for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int fn = 0; fn < WFN; ++fn) {
-        f32x16 c = acc[fm][fn];  // smallest products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][2][fn], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][fm], fb[S][1][fn], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][2][fm], fb[S][0][fn], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][1][fn], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][fm], fb[S][0][fn], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][fm], fb[S][0][fn], c, 0, 0, 0);
-        acc[fm][fn] = c;
-      }
+      for (int fm = 0; fm < WFM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < WFN; ++fn)
+          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][PA[q]][fm], fb[S][PB[q]][fn], acc[fm][fn], 0, 0, 0);
   }
 #define GPVAE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   // k-tile in buffer CUR.  HAS1 / HAS2: tiles t+1 / t+2 exist.

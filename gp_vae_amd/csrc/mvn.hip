@@ -158,6 +158,63 @@ __global__ void mvn_scale_kernel(int batch, const T *var, const T *ls, const int
   if (grad_ls) grad_ls[b] = bad ? dnan<T>() : acc2[2 * b + 1] / (T(2) * ls[b] * ls[b] * ls[b]);
 }
 
+
+// ---- a10 as one call: potential of gp_regression / regression and its gradient ---------------------------
+// q [chains, ldq] = (f [n], log var, log ls, log sigma) in NumPyro's unconstrained space
+// (inference.py:368-396, 407-424): priors LogNormal(0, 0.1), InverseGamma(4, 1), HalfNormal(0.1), latent
+// f ~ MVN(0, K), Gaussian likelihood on f[lik_idx] (lik_idx == NULL: every point).
+// gp_prep_kernel: var = e^u, ls = e^u into the workspace, f gathered contiguous.
+// gp_finish_kernel (one workgroup per chain): likelihood sums, priors, Jacobians -> U, dU/dq.
+template <typename T>
+__global__ void gp_prep_kernel(int64_t n, const T *q, int64_t ldq, T *f, T *var, T *ls) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[b * n + i] = q[b * ldq + i];
+  if (i == 0) {
+    var[b] = dexp<T>(q[b * ldq + n]);
+    ls[b] = dexp<T>(q[b * ldq + n + 1]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gp_finish_kernel(int64_t n, int64_t n_lik, const T *q, int64_t ldq,
+                                                        const T *y_lik, const int64_t *lik_idx,
+                                                        const T *logp, const T *gf, const T *gv,
+                                                        const T *gl, T *U, T *dU, int64_t lddu) {
+  __shared__ T red[4];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const T *qb = q + b * ldq;
+  T *db = dU + b * lddu;
+  const T uv = qb[n], ul = qb[n + 1], us = qb[n + 2];
+  const T var = dexp<T>(uv), ls = dexp<T>(ul), sig = dexp<T>(us);
+  const T isig = T(1) / sig;
+  for (int64_t i = tid; i < n; i += 256) db[i] = -gf[b * n + i];  // dU/df = -dlogMVN/df (+ likelihood below)
+  __syncthreads();
+  T sq = T(0);
+  for (int64_t j = tid; j < n_lik; j += 256) {
+    const int64_t i = lik_idx ? lik_idx[j] : j;
+    const T r = (y_lik[j] - qb[i]) * isig;
+    sq += r * r;
+    db[i] -= r * isig;  // indices are distinct: no two threads touch one entry
+  }
+  sq = wave_sum<T>(sq);
+  if ((tid & 63) == 0) red[tid >> 6] = sq;
+  __syncthreads();
+  if (tid == 0) {
+    sq = red[0] + red[1] + red[2] + red[3];
+    const T s0 = T(0.1), hl2p = T(0.9189385332046727), m = (T)n_lik;
+    const T lp_var = -dlog<T>(s0) - hl2p - uv * uv / (T(2) * s0 * s0);                     // LogNormal(0,.1) + Jacobian
+    const T lp_sig = T(0.6931471805599453) - hl2p - dlog<T>(s0) - T(0.5) * (sig / s0) * (sig / s0) + us;  // HalfNormal(.1)
+    const T lp_ls = T(-1.791759469228055) - T(4) * ul - T(1) / ls;                          // InverseGamma(4,1): -lgamma(4)
+    const T lp_lik = T(-0.5) * sq - m * us - m * hl2p;
+    U[b] = -(lp_var + lp_sig + lp_ls + logp[b] + lp_lik);
+    db[n] = -(-uv / (s0 * s0) + gv[b] * var);
+    db[n + 1] = -(T(-4) + T(1) / ls + gl[b] * ls);
+    db[n + 2] = -(T(1) - (sig / s0) * (sig / s0) + sq - m);
+  }
+}
+
 template <typename T>
 static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const void *x,
                    const void *f, const void *var, const void *ls, double jitter, void *logp,
@@ -232,4 +289,50 @@ extern "C" int gpvae_mvn_logp(void *stream, int dtype, int d, int64_t n, int bat
                                              grad_f, grad_var, grad_ls, info, work)
                             : run_mvn<double>(st, dtype, d, n, batch, x, f, var, ls, jitter, logp,
                                               grad_f, grad_var, grad_ls, info, work);
+}
+
+extern "C" int64_t gpvae_gp_potential_workspace_bytes(int dtype, int64_t n, int chains) {
+  if (n <= 0 || chains <= 0) return 0;
+  const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
+  // f [chains, n], var, ls, logp, grad_var, grad_ls [chains], grad_f [chains, n], then gpvae_mvn_logp's workspace
+  return round_up((int64_t)chains * (2 * n + 5) * es, 256) + gpvae_mvn_workspace_bytes(dtype, n, chains);
+}
+
+template <typename T>
+static int run_gp_potential(hipStream_t st, int dtype, int d, int64_t n, int chains, const void *x, const void *q,
+                            int64_t ldq, const void *y_lik, const int64_t *lik_idx, int64_t n_lik, double jitter,
+                            void *U, void *dU, int64_t lddu, int32_t *info, void *work) {
+  T *f = (T *)work, *var = f + (int64_t)chains * n, *ls = var + chains, *lp = ls + chains, *gv = lp + chains,
+    *gl = gv + chains, *gf = gl + chains;
+  void *mwork = (char *)work + round_up((int64_t)chains * (2 * n + 5) * (int64_t)sizeof(T), 256);
+  hipLaunchKernelGGL((gp_prep_kernel<T>), dim3((unsigned)cdiv(n, 256), (unsigned)chains), dim3(256), 0, st, n,
+                     (const T *)q, ldq, f, var, ls);
+  if (int rc = run_mvn<T>(st, dtype, d, n, chains, x, f, var, ls, jitter, lp, gf, gv, gl, info, mwork)) return rc;
+  hipLaunchKernelGGL((gp_finish_kernel<T>), dim3((unsigned)chains), dim3(256), 0, st, n, n_lik, (const T *)q, ldq,
+                     (const T *)y_lik, lik_idx, lp, gf, gv, gl, (T *)U, (T *)dU, lddu);
+  GPVAE_CHECK_LAUNCH("gpvae_gp_potential");
+  return 0;
+}
+
+extern "C" int gpvae_gp_potential(void *stream, int dtype, int d, int64_t n, int chains, const void *x,
+                                  const void *q, int64_t ldq, const void *y_lik, const int64_t *lik_idx,
+                                  int64_t n_lik, double jitter, void *U, void *dU, int64_t lddu,
+                                  int32_t *info, void *work) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_gp_potential: bad dtype %d", dtype);
+  GPVAE_REQUIRE(d == 1 || d == 2, 3, "gpvae_gp_potential: d must be 1 or 2");
+  GPVAE_REQUIRE(n >= 1, 4, "gpvae_gp_potential: n < 1");
+  GPVAE_REQUIRE(chains >= 0 && chains <= 65535, 5, "gpvae_gp_potential: chains out of range [0,65535]");
+  if (chains == 0) return 0;
+  GPVAE_REQUIRE(x && q && y_lik, 6, "gpvae_gp_potential: NULL input");
+  GPVAE_REQUIRE(ldq >= n + 3, 8, "gpvae_gp_potential: ldq < n + 3");
+  GPVAE_REQUIRE(n_lik >= 0 && n_lik <= n && (lik_idx != nullptr || n_lik == n), 11,
+                "gpvae_gp_potential: n_lik out of range, or lik_idx NULL with n_lik != n");
+  GPVAE_REQUIRE(U && dU, 13, "gpvae_gp_potential: U / dU is NULL");
+  GPVAE_REQUIRE(lddu >= n + 3, 15, "gpvae_gp_potential: lddu < n + 3");
+  GPVAE_REQUIRE(info, 16, "gpvae_gp_potential: info is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 17, "gpvae_gp_potential: work NULL or not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == GPVAE_F32
+             ? run_gp_potential<float>(st, dtype, d, n, chains, x, q, ldq, y_lik, lik_idx, n_lik, jitter, U, dU, lddu, info, work)
+             : run_gp_potential<double>(st, dtype, d, n, chains, x, q, ldq, y_lik, lik_idx, n_lik, jitter, U, dU, lddu, info, work);
 }

@@ -441,6 +441,17 @@ __global__ void latent_grad_kernel(int64_t count, T *MU, T *LS, const T *__restr
     LS[i] = dmu * eps[i] * SD[i] - T(1);
   }
 }
+// one launch clears what an ELBO evaluation accumulates into (loss word, split-K / replica buffers,
+// gradient vector): three hipMemsetAsync calls were three ~5 us launches on the step's critical path
+__global__ void zero3_kernel(uint32_t *a, int64_t na, uint32_t *b, int64_t nb, uint32_t *c, int64_t nc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += stride) {
+    if (i < na) a[i] = 0u;
+    else if (i < na + nb) b[i - na] = 0u;
+    else c[i - na - nb] = 0u;
+  }
+}
+
 static inline unsigned ew_blocks(int64_t count) {
   const int64_t b = cdiv(count, (int64_t)NTHREADS * 4);
   return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -679,8 +690,15 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   // constant of the data term: B*n*(log sigma + 0.5 log 2pi)
   const T loss_const = (T)((double)B * (double)n * (log(obs_sigma) + 0.9189385332046727));
 
-  (void)hipMemsetAsync(loss, 0, sizeof(T), st);
-  (void)hipMemsetAsync(W.H1, 0, sizeof(T) * (grads != nullptr ? W.zero_elems : B * h0), st);
+  {
+    constexpr int64_t WPE = sizeof(T) / 4;  // 32-bit words per element
+    const int64_t nh = WPE * (grads != nullptr ? W.zero_elems : B * h0);
+    const int64_t ng = grads != nullptr ? WPE * vae_param_count(n, h0, h1, z) : 0;
+    int64_t blocks = cdiv(WPE + nh + ng, 256 * 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)loss, WPE,
+                       (uint32_t *)W.H1, nh, (uint32_t *)grads, ng);
+  }
   {  // A1 += Y W1
     GemmArgs<T> g{};
     g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.H1; g.ldc = h0;
@@ -709,7 +727,6 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
     fused = grads != nullptr && h0 + 1 <= 64 && B % 128 == 0 && n % 64 == 0 &&
             (int64_t)(h0 + 1) * n * 4 < ((int64_t)1 << 31) && 32 * ldy * 4 < ((int64_t)1 << 31);
   }
-  if (grads != nullptr) (void)hipMemsetAsync(grads, 0, sizeof(T) * vae_param_count(n, h0, h1, z), st);
   if (fused) {
     if constexpr (sizeof(T) == 4) {
       VaeParams<T> G(grads, n, h0, h1, z);

@@ -183,7 +183,12 @@ class GPInference(Inference):
         f: [chains, n_obs]; log_var, log_ls, log_sigma: [chains].
         Returns (U [chains], dU/df [chains, n_obs], dU/dlog_var, dU/dlog_ls, dU/dlog_sigma)."""
         x_obs = self.x[self.obs_idx].contiguous()
-        return self._gp_potential(x_obs, self.y[self.obs_idx], None, f, log_var, log_ls, log_sigma)
+        n = x_obs.shape[0]
+        q = torch.cat([_as_device(f, self.dtype).reshape(-1, n)] +
+                      [_as_device(t, self.dtype).reshape(-1, 1) for t in (log_var, log_ls, log_sigma)], 1)
+        U, dU, info = ops.gp_potential(x_obs, q, self.y[self.obs_idx].contiguous(), None, 1.0e-5)
+        self.last_info = info
+        return U, dU[:, :n], dU[:, n], dU[:, n + 1], dU[:, n + 2]
 
     def _latent_gp_model(self, x_pts, y_lik, lik_idx):
         """The Potential of the latent-f model: unconstrained vector q = (f [n], log var, log ls,
@@ -194,10 +199,12 @@ class GPInference(Inference):
         q0[n + 1] = math.log(0.2723)
         q0[n + 2] = math.log(0.0674)
 
-        def fn(q):
-            U, dF, dV, dL, dS = self._gp_potential(x_pts, y_lik, lik_idx, q[:, :n], q[:, n], q[:, n + 1],
-                                                   q[:, n + 2])
-            return U, torch.cat([dF, dV[:, None], dL[:, None], dS[:, None]], 1)
+        y_lik = y_lik.contiguous()
+
+        def fn(q):  # one library call per evaluation (gpvae_gp_potential)
+            U, dU, info = ops.gp_potential(x_pts, q if q.stride(1) == 1 else q.contiguous(), y_lik, lik_idx, 1.0e-5)
+            self.last_info = info
+            return U, dU
 
         def unpack(smp):
             return {"f": smp[:, :n], "kernel_var": torch.exp(smp[:, n]),

@@ -423,6 +423,32 @@ def mvn_logp(x, f, var, ls, jitter=1.0e-5, grad=True):
     return logp, gf, gv, gl, info
 
 
+def gp_potential(x, q, y_lik, lik_idx=None, jitter=1.0e-5):
+    """(U [chains], dU/dq [chains, n+3], info) of the latent-f GP regression model for rows
+    q = (f [n], log var, log ls, log sigma): gpvae_gp_potential (inference.py:359-424)."""
+    _dev(x, q, y_lik, lik_idx)
+    x = _points(x)
+    n, d = x.shape
+    if q.dim() != 2 or q.shape[1] != n + 3 or q.stride(1) != 1 or q.dtype != x.dtype:
+        raise GpvaeError("gp_potential: q must be [chains, n+3], unit column stride, dtype of x")
+    chains = q.shape[0]
+    y_lik = y_lik.contiguous()
+    n_lik = y_lik.numel()
+    if lik_idx is not None:
+        lik_idx = lik_idx.contiguous()
+        if lik_idx.dtype != torch.long or lik_idx.numel() != n_lik:
+            raise GpvaeError("gp_potential: lik_idx must be int64 with one entry per observation")
+    lib = _lib.load()
+    work = torch.empty(max(16, lib.gpvae_gp_potential_workspace_bytes(_dt(x), n, chains)), dtype=torch.uint8, device=x.device)
+    U = torch.empty(chains, dtype=x.dtype, device=x.device)
+    dU = torch.empty((chains, n + 3), dtype=x.dtype, device=x.device)
+    info = torch.empty(chains, dtype=torch.int32, device=x.device)
+    check(lib.gpvae_gp_potential(_stream(), _dt(x), d, n, chains, _p(x), _p(q), q.stride(0), _p(y_lik), _p(lik_idx),
+                                 n_lik, float(jitter), _p(U), _p(dU), dU.stride(0), _p(info), _p(work)),
+          "gpvae_gp_potential")
+    return U, dU, info
+
+
 # ---- a5-a7, a11: VAE -----------------------------------------------------------------------------------
 def vae_param_count(n, h0, h1, z):
     return int(_lib.load().gpvae_vae_param_count(n, h0, h1, z))

@@ -279,6 +279,9 @@ class StepEngine():
         self.work = ops.VaeWorkspace(B, n, self.h0, self.h1, self.z, dtype, dev)
         self.overlap = overlap
         self.s_gp = torch.cuda.Stream(device=dev) if overlap else None
+        self.s_rng = torch.cuda.Stream(device=dev) if overlap else None
+        self.ev_drawn, self.ev_rng = torch.cuda.Event(), torch.cuda.Event()
+        self._rng_pending = False
         self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # factors of group slot s are ready
         self.ev_free = [torch.cuda.Event() for _ in range(2)]    # group slot s has been consumed
         self.ev_copied = [torch.cuda.Event() for _ in range(2)]  # slot s's hyper upload is done
@@ -334,17 +337,29 @@ class StepEngine():
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
-    def _produce(self, key, slot, i, last_of_group, buf):
-        """Normals and the B draws of one step into draw buffer `buf` (main stream)."""
-        main = torch.cuda.current_stream()
-        if self.overlap and i == 0:
-            main.wait_event(self.ev_ready[slot])
+    def _normals(self, key, buf):
+        """The step's standard normals (Philox streams keyed by rank, key, purpose): E (as bf16 planes on the
+        bf16 x 3 path), E', eps_z into draw buffer `buf`."""
         if self.b3:
             ops.randn_b3(None, out=self.E3, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
         else:
             ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
         ops.randn(None, out=self.E2, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 2))
         ops.randn(None, out=self.ezbuf[buf], seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
+
+    def _produce(self, key, slot, i, last_of_group, buf, next_key=None):
+        """The B draws of one step into draw buffer `buf` (main stream).  The normals of the NEXT step are
+        generated on a side stream as soon as this draw has read E / E' — beside the ELBO chain of this
+        step, whose small latency-bound kernels leave most CUs idle (they were 36 us of the main
+        stream's critical path)."""
+        main = torch.cuda.current_stream()
+        if self.overlap and i == 0:
+            main.wait_event(self.ev_ready[slot])
+        if self._rng_pending:
+            main.wait_event(self.ev_rng)      # this step's normals came from the side stream
+            self._rng_pending = False
+        else:
+            self._normals(key, buf)
         K = self.Kbuf[slot][i]
         sig = self.hyper_dev[slot][2, i:i + 1]
         lib = _lib.load()
@@ -362,6 +377,13 @@ class StepEngine():
         if self.draw_events is not None:
             ev[1].record(main)
             self.draw_events.append(ev)
+        if self.overlap and next_key is not None:
+            self.ev_drawn.record(main)
+            self.s_rng.wait_event(self.ev_drawn)
+            with torch.cuda.stream(self.s_rng):
+                self._normals(next_key, buf ^ 1)
+                self.ev_rng.record(self.s_rng)
+            self._rng_pending = True
         if self.overlap and last_of_group:
             self.ev_free[slot].record(main)
 
@@ -413,7 +435,8 @@ class StepEngine():
             if gi + 1 < len(groups):
                 self._issue_factors(groups[gi + 1], (gi + 1) & 1)
             for i, key in enumerate(grp):
-                self._produce(key, slot, i, i == len(grp) - 1, t & 1)
+                nxt = grp[i + 1] if i + 1 < len(grp) else (groups[gi + 1][0] if gi + 1 < len(groups) else None)
+                self._produce(key, slot, i, i == len(grp) - 1, t & 1, nxt)
                 if pending is not None:
                     self._learn_finish(pending[0], state, train)
                 pending = (self._learn_start(t & 1, state, train, t),)

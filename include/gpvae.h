@@ -214,6 +214,20 @@ int gpvae_mvn_logp(void *stream, int dtype, int d, int64_t n, int batch, const v
                    const void *f, const void *var, const void *ls, double jitter, void *logp,
                    void *grad_f, void *grad_var, void *grad_ls, int32_t *info, void *work);
 
+/* ---- a10 as one call: potential energy of gp_regression / regression and its gradient -------------------
+ * Replaces what NUTS evaluates per leapfrog step for GPInference.gp_regression (inference.py:400-424)
+ * and, with lik_idx, for GPInference.regression (inference.py:359-397), in NumPyro's unconstrained space:
+ * q [chains, ldq] = (f [n], log kernel_var, log kernel_length, log kernel_sigma); sites kernel_var ~
+ * LogNormal(0, 0.1), kernel_sigma ~ HalfNormal(0.1), kernel_length ~ InverseGamma(4, 1),
+ * f ~ MVN(0, kernel(x, x, var, ls) + jitter I), y_lik[j] ~ Normal(f[lik_idx[j]], sigma) (lik_idx NULL:
+ * every point, n_lik == n).  U[c] = potential energy, dU [chains, lddu] = dU/dq.  gpvae_mvn_logp plus two
+ * small kernels (exp / gather, and priors + likelihood + Jacobians); a chain whose K is not positive
+ * definite gets NaN and info > 0.  work: gpvae_gp_potential_workspace_bytes().                         */
+int64_t gpvae_gp_potential_workspace_bytes(int dtype, int64_t n, int chains);
+int gpvae_gp_potential(void *stream, int dtype, int d, int64_t n, int chains, const void *x, const void *q,
+                       int64_t ldq, const void *y_lik, const int64_t *lik_idx, int64_t n_lik,
+                       double jitter, void *U, void *dU, int64_t lddu, int32_t *info, void *work);
+
 /* ---- a5+a6: VAE ELBO forward (+ backward) ---------------------------------------------------------
  * Replaces vae_encoder/vae_decoder (src/model/vae.py:72-96) and vae_model+vae_guide under
  * Trace_ELBO (vae.py:98-137,213-218): one-particle ELBO summed over batch and dims, obs noise

@@ -241,6 +241,17 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
     for c in range(3):
         qq = q[c].cpu().numpy()
         assert abs(U[c].item() - orc.gp_regression_potential(x[obs], y[obs], qq[:12], qq[12], qq[13], qq[14])) < 1e-9 * abs(U[c].item())
+    # gpvae_gp_potential (one call) against the composed path (gpvae_mvn_logp + glue), f64 and f32
+    U2, dF2, dV2, dL2, dS2 = inf._gp_potential(inf.x[inf.obs_idx].contiguous(), inf.y[inf.obs_idx], None, q[:, :12], q[:, 12], q[:, 13], q[:, 14])
+    assert rel(U, U2.cpu().numpy()) < 1e-12 and rel(dU, torch.cat([dF2, dV2[:, None], dL2[:, None], dS2[:, None]], 1).cpu().numpy()) < 1e-9
+    inf32 = GPInference(exp_kernel2, 1, x, y, obs, args, seed=5, dtype=torch.float32)
+    # (f drawn near the prior scale: a random f would make f^T K^-1 f ~ 1e6 and float32 meaningless)
+    Lp = np.linalg.cholesky(orc.exp_kernel2(x[obs], x[obs], 1.0, 0.27, 1e-5))
+    q32 = torch.tensor(np.concatenate([(Lp @ rng.standard_normal((12, 3))).T, np.tile([0.0, np.log(0.27), np.log(0.07)], (3, 1))], 1),
+                       dtype=torch.float32, device=DEV)
+    U32, dU32 = inf32.gp_regression(inf32.x[inf32.obs_idx], inf32.y[inf32.obs_idx])(q32)
+    U64, dU64 = pot(q32.double())
+    assert rel(U32, U64.cpu().numpy()) < 1e-3 and rel(dU32[:, :12], dU64[:, :12].cpu().numpy()) < 2e-2
     # full-grid model (inference.py:359-397): latent f on all n points, likelihood on the observed ones
     potf = inf.regression(y=inf.y, obs_idx=inf.obs_idx)
     qf = potf.init[None, :] + 0.01 * torch.randn(2, n + 3, dtype=torch.float64, device=DEV)
