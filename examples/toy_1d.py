@@ -7,7 +7,7 @@
     inference = VAEInference(decoder, decoder_params, z_dim, d, x, y, obs_idx, mcmc_args, seed)
     prior_pred, post_pred = inference.fit(plot=False)         # toy_examples.py:180-200
 
-Everything numerical runs in libgpvae_hip (MI355X); NUTS is replaced by the batched HMC driver.
+Everything numerical runs in libgpvae_hip (MI355X); NUTS is the batched restatement in gp_vae_amd/nuts.py.
 usage: python examples/toy_1d.py [--num-epochs 5 --num-train 200 --num-test 50 --noise 0.001]
 """
 import argparse
@@ -69,7 +69,7 @@ def main():
     post_mean = post_pred.mean(0).cpu().numpy()
     rmse_obs = float(np.sqrt(np.mean((post_mean[obs_idx] - y_true[obs_idx]) ** 2)))
     rmse_all = float(np.sqrt(np.mean((post_mean - y_true) ** 2)))
-    print("VAEInference.fit (HMC, 4 chains): %.2f s, accept %.2f, divergent %d" %
+    print("VAEInference.fit (NUTS, 4 chains): %.2f s, accept %.2f, divergent %d" %
           (t_mcmc, inf.mcmc_info["accept_prob"].mean().item(), inf.mcmc_info["divergent"]))
     print("         posterior-mean RMSE at the 10 observed points %.3f, over all %d points %.3f (prior draws: %.3f)" %
           (rmse_obs, a.n, rmse_all, float(np.sqrt(np.mean((prior_pred.mean(0).cpu().numpy() - y_true) ** 2)))))

@@ -7,8 +7,8 @@ evaluation:
                                             sharded over ranks with no collective
   * VAEInference.potential_and_grad      -> gpvae_decoder_fwd / gpvae_decoder_vjp batched over chains
                                             (what NUTS asks of VAEInference.regression per leapfrog)
-The NUTS transition itself is NumPyro's (third party, not in the reference tree): `run_mcmc` raises
-unless numpyro is importable.  Plotting (inference.py:149-204) is out of scope.
+The NUTS transition itself is NumPyro's (third party, not in the reference tree): `run_mcmc` drives the
+batched restatement in gp_vae_amd/nuts.py (or the plain HMC of hmc.py) over the same potentials.  Plotting (inference.py:149-204) is out of scope.
 """
 import math
 
@@ -18,6 +18,7 @@ import torch.distributed as dist
 
 from . import ops
 from .hmc import hmc
+from .nuts import nuts, uniforms_per_iteration
 from ._lib import GpvaeError
 from .gp import _as_device, _key_parts, _seed_of, exp_kernel2
 from .parallel import dist_info, shard
@@ -70,15 +71,19 @@ class Inference():
 
     def _mcmc(self, rng_key, potential, q0=None):
         """mcmc_args of the reference (num_warmup, num_samples, num_chains, thinning;
-        inference.py:86-93) driving the batched HMC of gp_vae_amd.hmc (NUTS is third-party code
-        that is absent here — same target, different trajectory rule).  q0: [dim] start, jittered
-        per chain.  With torch.distributed initialised the chains are sharded round-robin over the
-        ranks (no collective; chain c keeps its start point and its own random
-        stream whatever the world size) and each rank returns its own chains' samples
-        [num_samples // thinning * local_chains, dim], chains concatenated as mcmc.get_samples()
-        does; the host concatenates ranks if it wants all of them."""
+        inference.py:86-93) driving the batched NUTS of gp_vae_amd.nuts (numpyro.infer.NUTS is third-party
+        code that is absent here; the module restates the published algorithm).  Extra keys:
+        "kernel": "nuts" (default) | "hmc" (gp_vae_amd.hmc, fixed-length trajectories), "max_tree_depth"
+        (10, NumPyro's default), "num_leapfrog" (hmc).  q0: [dim] start, jittered per chain.  With
+        torch.distributed initialised the chains are sharded round-robin over the ranks (SURVEY.md §8e:
+        no collective; chain c keeps its start point and its own random stream whatever the world size)
+        and each rank returns its own chains' samples [num_samples // thinning * local_chains, dim],
+        chains concatenated as mcmc.get_samples() does; the host concatenates ranks if it wants all."""
         a = self.mcmc_args
         chains = int(a.get("num_chains", 1))
+        kernel = a.get("kernel", "nuts")
+        if kernel not in ("nuts", "hmc"):
+            raise ValueError("mcmc_args['kernel'] must be 'nuts' or 'hmc'")
         if q0 is None:
             q0 = potential.init
         mine = list(shard(chains))
@@ -87,22 +92,28 @@ class Inference():
         if not mine:
             self.mcmc_info = {}
             return q0.new_empty((0, q0.numel())), {}
-        rows0 = torch.as_tensor(mine, dtype=torch.long, device=q0.device)
-        start = q0[None, :] + 0.01 * ops.randn((chains, q0.numel()), q0.dtype, q0.device, seed=seed,
-                                               stream_id=0x1417 << 32)[rows0]
         rows = torch.as_tensor(mine, dtype=torch.long, device=q0.device)
+        start = q0[None, :] + 0.01 * ops.randn((chains, q0.numel()), q0.dtype, q0.device, seed=seed,
+                                               stream_id=0x1417 << 32)[rows]
         D = q0.numel()
+        depth = int(a.get("max_tree_depth", 10))
+        nu = uniforms_per_iteration(depth) if kernel == "nuts" else 1
 
         def noise_fn(it):
             # Philox rows of ALL chains, this rank keeps its own: element (chain c, j) of iteration `it`
-            # is the same number on any world size
-            g = ops.randn((chains, D + 1), q0.dtype, q0.device, seed=seed + 1, stream_id=(0x1418 << 32) | it)[rows]
-            unif = 0.5 * (1.0 + torch.erf(g[:, D] * (1.0 / math.sqrt(2.0))))
-            return g[:, :D], unif
+            # is the same number on any world size.  Uniforms = Phi(normal).
+            g = ops.randn((chains, D + nu), q0.dtype, q0.device, seed=seed + 1, stream_id=(0x1418 << 32) | it)[rows]
+            unif = 0.5 * (1.0 + torch.erf(g[:, D:] * (1.0 / math.sqrt(2.0))))
+            return g[:, :D], (unif if kernel == "nuts" else unif[:, 0])
 
-        smp, info = hmc(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
-                        thinning=int(a.get("thinning", 1)), num_leapfrog=int(a.get("num_leapfrog", 16)),
-                        seed=seed + 1, noise_fn=noise_fn)
+        if kernel == "nuts":
+            smp, info = nuts(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
+                             thinning=int(a.get("thinning", 1)), max_tree_depth=depth, seed=seed + 1,
+                             noise_fn=noise_fn)
+        else:
+            smp, info = hmc(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
+                            thinning=int(a.get("thinning", 1)), num_leapfrog=int(a.get("num_leapfrog", 16)),
+                            seed=seed + 1, noise_fn=noise_fn)
         self.mcmc_info = info
         return smp.permute(1, 0, 2).reshape(-1, q0.numel()), info
 

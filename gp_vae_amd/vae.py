@@ -205,6 +205,50 @@ def decoder_flat_from_list(params_list, dtype=None, device=None):
     return torch.cat(parts).contiguous()
 
 
+def save_decoder_params(path, params_list, format="npz"):
+    """Write the decoder parameters `VAE.fit()` returns — the stax list [(W,b),(),(W,b),(),(W,b)] the
+    reference pickles after training (toy_examples.py:161-165, 2d_examples.py) — to `path`.
+
+    format="npz" (default): six plain arrays V1,c1,V2,c2,V3,c3, readable with numpy.load(allow_pickle=
+    False) — what load_decoder_params reads.  format="pickle": the reference's own file format (the
+    same list with numpy arrays, pickle protocol 4), for handing a decoder trained here to the
+    reference's scripts, whose `pickle.load` + `decoder(decoder_params, z)` accept it as is."""
+    (V1, c1), _, (V2, c2), _, (V3, c3) = params_list
+    arrs = [np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a))
+            for a in (V1, c1, V2, c2, V3, c3)]
+    if format == "npz":
+        with open(path, "wb") as fh:
+            np.savez(fh, V1=arrs[0], c1=arrs[1], V2=arrs[2], c2=arrs[3], V3=arrs[4], c3=arrs[5])
+    elif format == "pickle":
+        import pickle
+        with open(path, "wb") as fh:
+            pickle.dump([(arrs[0], arrs[1]), (), (arrs[2], arrs[3]), (), (arrs[4], arrs[5])], fh, protocol=4)
+    else:
+        raise ValueError("format must be 'npz' or 'pickle'")
+
+
+def load_decoder_params(path, dtype=None, device=None):
+    """Read a decoder written by save_decoder_params(format="npz") back as the stax list (tensors on
+    `device`).  Pickle files are not read here — unpickling runs code from the file, and the reference's
+    decoder files hold jax device arrays that only a full unpickler with jax installed can rebuild;
+    convert them once, where they are trusted, with `numpy.savez` of the six arrays."""
+    with open(path, "rb") as fh:
+        if fh.read(4) != b"PK\x03\x04":
+            raise GpvaeError("load_decoder_params reads the .npz files save_decoder_params writes; %r is not "
+                             "one (a pickle is not loaded: convert it to six arrays V1,c1,V2,c2,V3,c3)" % (path,))
+    with np.load(path, allow_pickle=False) as z:
+        names = ("V1", "c1", "V2", "c2", "V3", "c3")
+        missing = [k for k in names if k not in z.files]
+        if missing:
+            raise GpvaeError("decoder file %r lacks arrays %s" % (path, missing))
+        a = [z[k] for k in names]
+    if not (a[0].ndim == a[2].ndim == a[4].ndim == 2 and a[0].shape[1] == a[2].shape[0] == a[1].shape[0]
+            and a[2].shape[1] == a[4].shape[0] == a[3].shape[0] and a[4].shape[1] == a[5].shape[0]):
+        raise GpvaeError("decoder file %r: layer shapes do not chain: %s" % (path, [x.shape for x in a]))
+    t = [_as_device(x, dtype) if device is None else torch.as_tensor(x, dtype=dtype, device=device) for x in a]
+    return [(t[0], t[1]), (), (t[2], t[3]), (), (t[4], t[5])]
+
+
 class StepEngine():
     """One training/evaluation step = gram -> potrf -> draw -> ELBO (-> all-reduce -> Adam).
 

@@ -695,9 +695,9 @@ def test_vaeinference_potential_gradient(ops):
     assert rel(inf.predict(Z), orc.decoder(p, Z)) < 1e-12
 
 
-def test_inference_fit_surface_with_hmc(ops):
+def test_inference_fit_surface_with_nuts(ops):
     """The reference's end-to-end inference calls (VAEInference.fit, GPInference.gp_fit) run with the
-    batched HMC driver in NUTS's place: shapes of what they return, no divergence, and the posterior
+    batched NUTS of gp_vae_amd/nuts.py in NumPyro's place: shapes of what they return, no divergence, and the posterior
     concentrates on the data (posterior-mean error at the observed points well below the prior's)."""
     from gp_vae_amd.gp import exp_kernel2
     from gp_vae_amd.inference import GPInference, VAEInference
@@ -707,9 +707,10 @@ def test_inference_fit_surface_with_hmc(ops):
     obs = np.sort(rng.permutation(n)[:20])
     truth = np.sin(6 * x)
     y = np.full(n, np.nan); y[obs] = truth[obs] + 0.05 * rng.standard_normal(20)
-    args = {"num_warmup": 150, "num_samples": 100, "num_chains": 4, "thinning": 2}
+    args = {"num_warmup": 150, "num_samples": 100, "num_chains": 4, "thinning": 2, "max_tree_depth": 6}
     inf = GPInference(exp_kernel2, 1, x, y, obs, args, seed=5, dtype=torch.float64)
     means, preds = inf.gp_fit(plot=False)
+    assert inf.mcmc_info["leapfrogs_per_iteration"].mean().item() >= 1.0  # the NUTS driver ran
     # proposals that leave the positive-definite region come back NaN and are rejected: a few per cent
     assert means.shape == preds.shape == (200, n - 20) and inf.mcmc_info["divergent"] < 50
     mask = np.ones(n, bool); mask[obs] = False

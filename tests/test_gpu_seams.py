@@ -232,7 +232,7 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
     x = np.arange(n) / n
     obs = np.sort(rng.permutation(n)[:12])
     y = np.full(n, np.nan); y[obs] = np.sin(6 * x[obs]) + 0.05 * rng.standard_normal(12)
-    args = {"num_warmup": 30, "num_samples": 20, "num_chains": 4, "thinning": 1}
+    args = {"num_warmup": 30, "num_samples": 20, "num_chains": 4, "thinning": 1, "max_tree_depth": 5}
     inf = GPInference(exp_kernel2, 1, x, y, obs, args, seed=5, dtype=torch.float64)
     pot = inf.gp_regression(inf.x[inf.obs_idx], inf.y[inf.obs_idx])
     assert isinstance(pot, Potential) and pot.init.shape == (15,)
@@ -270,7 +270,7 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
     # chain sharding: rank r of 2 runs chains r, r+2 and gets the very chains of the one-process run.  Few
     # iterations: the batch shape changes the order of the split-K sums inside gpvae_mvn_logp, and long HMC
     # runs amplify that rounding (an accept decision may flip) — 6 iterations keep it at rounding level
-    inf.mcmc_args = {"num_warmup": 3, "num_samples": 3, "num_chains": 4, "thinning": 1}
+    inf.mcmc_args = {"num_warmup": 3, "num_samples": 3, "num_chains": 4, "thinning": 1, "max_tree_depth": 3}
     whole = inf.gp_run_mcmc(7, inf.x[inf.obs_idx], inf.y[inf.obs_idx], model=inf.gp_regression)["f"].reshape(4, 3, 12)
     for r in range(2):
         monkeypatch.setattr(parallel, "dist_info", lambda r=r: (r, 2))
@@ -282,7 +282,7 @@ def test_regression_seams_and_chain_sharding(monkeypatch):
     nz, h1, h0 = 6, 9, 12
     p = orc.init_params(rng, n, h0, h1, nz, np.float64)
     dec = [(50 * p["V1"], p["c1"]), (), (50 * p["V2"], p["c2"]), (), (50 * p["V3"], p["c3"])]
-    vinf = VAEInference(None, dec, nz, 1, x, y, obs, args, seed=6, dtype=torch.float64)
+    vinf = VAEInference(None, dec, nz, 1, x, y, obs, dict(args, kernel="hmc"), seed=6, dtype=torch.float64)
     vp = vinf.regression(y=vinf.y, obs_idx=vinf.obs_idx)
     Z, u = rng.standard_normal((5, nz)), np.log(0.1) + 0.1 * rng.standard_normal(5)
     Uv, _ = vp(torch.tensor(np.concatenate([Z, u[:, None]], 1), device=DEV))

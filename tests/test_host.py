@@ -122,6 +122,72 @@ def test_hmc_recovers_a_gaussian_target():
     assert a.shape == (10, 2, 3) and torch.equal(a, b)
 
 
+def test_nuts_recovers_an_anisotropic_gaussian():
+    """The batched NUTS (restated algorithm behind numpyro.infer.NUTS, inference.py:84-95) on
+    N(mu, diag(s^2)) with scales over two decades: moments within Monte-Carlo error, the diagonal mass
+    matrix finds the variances, no divergence, chains independent of their batch neighbours."""
+    from gp_vae_amd.nuts import nuts, _ckpt_range, uniforms_per_iteration
+    assert [_ckpt_range(k) for k in (0, 1, 6, 7, 13)] == [(1, 0), (0, 0), (3, 2), (0, 2), (2, 2)]
+    assert uniforms_per_iteration(3) == 14
+    mu = torch.tensor([1.0, -2.0, 0.0, 5.0], dtype=torch.float64)
+    sd = torch.tensor([0.1, 1.0, 3.0, 10.0], dtype=torch.float64)
+
+    def pot(q):
+        r = (q - mu) / sd
+        return 0.5 * (r * r).sum(1), r / sd
+
+    smp, info = nuts(pot, torch.zeros((16, 4), dtype=torch.float64), 200, 200, max_tree_depth=7, seed=3)
+    assert smp.shape == (200, 16, 4) and info["divergent"] == 0
+    assert 0.6 < info["accept_prob"].mean().item() < 0.99
+    flat = smp.reshape(-1, 4)
+    assert torch.all((flat.mean(0) - mu).abs() < 0.1 * sd)
+    assert torch.allclose(flat.std(0), sd, rtol=0.1)
+    assert torch.allclose(info["inverse_mass"].mean(0), sd ** 2, rtol=0.5)
+    assert 1.0 <= info["leapfrogs_per_iteration"].mean().item() < 2 ** 7
+
+    # a chain's numbers do not depend on which chains share its batch (masked lock-step trees)
+    def noise(rows):
+        def fn(it):
+            g = torch.Generator().manual_seed(1000 + it)
+            z = torch.randn((6, 4), dtype=torch.float64, generator=g)
+            u = torch.rand((6, uniforms_per_iteration(5)), dtype=torch.float64, generator=g)
+            return z[rows], u[rows]
+        return fn
+    q0 = torch.linspace(-1, 1, 24, dtype=torch.float64).reshape(6, 4)
+    full, _ = nuts(pot, q0, 30, 10, max_tree_depth=5, noise_fn=noise(torch.arange(6)))
+    part, _ = nuts(pot, q0[[1, 4]], 30, 10, max_tree_depth=5, noise_fn=noise(torch.tensor([1, 4])))
+    assert torch.equal(full[:, [1, 4]], part)
+
+
+def test_decoder_param_files_round_trip(tmp_path):
+    """Decoder-parameter I/O (the reference pickles VAE.fit()'s list, toy_examples.py:161-169): the npz form
+    round-trips bit for bit, the pickle form is the reference's layout with plain numpy arrays, and the
+    loader refuses anything that is not its own npz."""
+    import pickle
+    from gp_vae_amd._lib import GpvaeError
+    from gp_vae_amd.vae import load_decoder_params, save_decoder_params
+    rng = np.random.default_rng(0)
+    shapes = [(10, 30), (30,), (30, 35), (35,), (35, 300), (300,)]
+    a = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    lst = [(torch.tensor(a[0]), torch.tensor(a[1])), (), (a[2], a[3]), (), (a[4], a[5])]
+    f = str(tmp_path / "dec.npz")
+    save_decoder_params(f, lst)
+    back = load_decoder_params(f, device="cpu")
+    assert [len(t) for t in back] == [2, 0, 2, 0, 2]
+    flat = [back[0][0], back[0][1], back[2][0], back[2][1], back[4][0], back[4][1]]
+    assert all(np.array_equal(t.numpy(), x) for t, x in zip(flat, a))
+    g = str(tmp_path / "dec.pkl")
+    save_decoder_params(g, lst, format="pickle")
+    with open(g, "rb") as fh:  # a file this test wrote
+        ref = pickle.load(fh)
+    assert ref[1] == () and ref[3] == () and isinstance(ref[0][0], np.ndarray) and np.array_equal(ref[4][0], a[4])
+    with pytest.raises(GpvaeError):
+        load_decoder_params(g, device="cpu")
+    np.savez(str(tmp_path / "bad.npz"), V1=a[0], c1=a[1], V2=a[4], c2=a[3], V3=a[4], c3=a[5])
+    with pytest.raises(GpvaeError):
+        load_decoder_params(str(tmp_path / "bad.npz"), device="cpu")
+
+
 def _run_bench(args, env_extra=None, timeout=240):
     import subprocess
     import sys
