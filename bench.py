@@ -168,6 +168,12 @@ def extras(ops, x, dev):
                     "GB_per_s": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / PEAK_HBM_GBS,
                     "bound": "hbm write"}
         del Kb
+    # a2: aggregated (cell-averaged) kernel, 32 x 32 cells of 16 sample points each: 2.7e8 kernel evaluations
+    # for a 4 MiB matrix — bound by the vector ALU's sqrt / exp issue, not by memory
+    pa = ops.randn((1024, 16, 2), torch.float32, dev, seed=3) * 0.01 + x[::4, None, :].to(torch.float32)
+    t = _event_time(lambda: ops.gram_agg(pa, 1.0, 0.3, 1e-6), 20)
+    out["gram_agg"] = {"kernel": "gram_agg_kernel", "n_cells": 1024, "m": 16, "ms": t * 1e3,
+                       "kernel_evals_per_s": 1024 * 1024 * 256 / t, "bound": "valu (sqrt + exp per evaluation)"}
     # C2: 1D n = 1024, B = 4096, reference MLP 35/30/10, whole training step
     x1 = torch.arange(1024, dtype=torch.float32, device=dev) / 1024
     eng = StepEngine(x1, 1e-4, (35, 30, 10), 4096, LR, dtype=torch.float32, seed=1, group=16)

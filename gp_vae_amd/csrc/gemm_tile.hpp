@@ -34,6 +34,11 @@ template <typename T> struct GemmArgs {
   int negate;           // C - A B (EPI_FUSED with addc, EPI_ATOMIC)
   const T *mask;        // keep where mask > 0, else 0 (nullptr: keep all)
   int64_t ldm;
+  // EPI_ATOMIC with slab > 0: k-slice z STORES its partial tile at C[z * slab + index] instead of adding
+  // it to C with float atomics; the caller sums the slices in a fixed order (slab_sum_kernel, or the
+  // consumer itself) — the same bits on every run
+  int64_t slab = 0;
+  T *loss_part = nullptr;  // EPI_DF: workgroup w stores its part of the loss at loss_part[w] (no atomic)
 };
 
 constexpr int GBM = 128, GBN = 64;
@@ -179,7 +184,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
         if constexpr (EPI == EPI_STORE) {
           if (in) g.C[ci] = v;
         } else if constexpr (EPI == EPI_ATOMIC) {
-          if (in) atomicAdd(&g.C[ci], g.negate ? -v : v);
+          if (g.slab > 0) {
+            if (in) g.C[(int64_t)blockIdx.z * g.slab + ci] = g.negate ? -v : v;
+          } else if (in) {
+            atomicAdd(&g.C[ci], g.negate ? -v : v);
+          }
         } else if constexpr (EPI == EPI_BIAS) {
           if (in) g.C[row * g.ldc + col] = v + g.bias[col];
         } else if constexpr (EPI == EPI_FUSED) {
@@ -205,14 +214,59 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
     lsum = wave_sum<T>(lsum);
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
-    if (tid == 0) atomicAdd(g.loss, T(0.5) * g.inv_var * (red[0] + red[1] + red[2] + red[3]));
+    if (tid == 0) {
+      const T part = T(0.5) * g.inv_var * (red[0] + red[1] + red[2] + red[3]);
+      if (g.loss_part != nullptr) g.loss_part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = part;
+      else atomicAdd(g.loss, part);
+    }
   }
 }
 
+// number of k-slices launch_gemm makes of a K-long product asked to split `splitk` ways
+template <typename T> static inline int gemm_slices(int64_t K, int splitk) {
+  constexpr int GBK = GemmK<T>::BK;
+  if (splitk < 1) splitk = 1;
+  int64_t kchunk = round_up(cdiv(K, (int64_t)splitk), (int64_t)GBK);
+  if (kchunk < GBK) kchunk = GBK;
+  return (int)(K > 0 ? cdiv(K, kchunk) : 1);
+}
+
+// sum over s < ns of p[s * slab + e], s ascending; eight loads in flight at a time (a plain loop waits for
+// every load before it issues the next: 16 slabs were 16 L2 round trips)
+template <typename T>
+__device__ __forceinline__ T slab_sum_at(const T *__restrict__ p, int ns, int64_t slab, int64_t e) {
+  T v = T(0);
+  int s = 0;
+  for (; s + 8 <= ns; s += 8) {
+    T a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = p[(int64_t)(s + u) * slab + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += a[u];
+  }
+  for (; s < ns; ++s) v += p[(int64_t)s * slab + e];
+  return v;
+}
+
+// dst[i] = sum over s < ns of src[s * slab + i], s ascending (the fixed-order partner of slab stores)
+template <typename T>
+__global__ void slab_sum_kernel(T *dst, const T *__restrict__ src, int64_t count, int ns, int64_t slab) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = slab_sum_at<T>(src, ns, slab, i);
+}
+template <typename T>
+static void launch_slab_sum(hipStream_t st, T *dst, const T *src, int64_t count, int ns, int64_t slab) {
+  if (count <= 0) return;
+  int64_t blocks = cdiv(count, (int64_t)256 * 2);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((slab_sum_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, dst, src, count, ns, slab);
+}
+
+// returns the number of k-slices launched (= slabs written when g.slab > 0)
 template <typename T, bool AKC, bool BKC, int EPI, int BM = 128>
-static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
+static int launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
   constexpr int GBM = BM;
-  if (g.M <= 0 || g.N <= 0) return;
+  if (g.M <= 0 || g.N <= 0) return 0;
   if (splitk < 1) splitk = 1;
   constexpr int GBK = GemmK<T>::BK;
   int64_t kchunk = round_up(cdiv(g.K, splitk), GBK);
@@ -225,6 +279,7 @@ static void launch_gemm(hipStream_t st, GemmArgs<T> g, int splitk) {
     hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, true, BM>), grid, dim3(NTHREADS), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, EPI, false, BM>), grid, dim3(NTHREADS), 0, st, g);
+  return (int)nz;
 }
 
 template <typename T> static inline bool mc_vec_ok(const void *base, int64_t ld) {

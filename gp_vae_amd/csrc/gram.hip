@@ -132,7 +132,7 @@ __global__ __launch_bounds__(AGG_T *AGG_T) void gram_agg_kernel(
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *prow = reinterpret_cast<T *>(smem_raw);      // [AGG_T][m][D]
   T *pcol = prow + (size_t)AGG_T * m * D;         // [AGG_T][m][D]
-  const T var = var_p[0], ls = ls_p[0];
+  const T var = var_p[0], inv_ls = T(1) / ls_p[0];
   const int64_t i0 = (int64_t)blockIdx.y * AGG_T, j0 = (int64_t)blockIdx.x * AGG_T;
   const int tid = threadIdx.y * AGG_T + threadIdx.x;
   const int per = AGG_T * m * D;
@@ -159,8 +159,7 @@ __global__ __launch_bounds__(AGG_T *AGG_T) void gram_agg_kernel(
         const T dlt = xa[e] - pj[bb * D + e];
         s += dlt * dlt;
       }
-      const T q = dsqrt<T>(s) / ls;
-      acc += var * dexp<T>(T(-0.5) * (q * q));
+      acc += var * GramMath<T>::expq(s, inv_ls);  // the arithmetic of gram_se (a1), entry by entry
     }
   }
   // every m x m block is square, so the literal code adds jitter to its m diagonal entries:

@@ -61,7 +61,8 @@ __device__ __forceinline__ void dense_bwd_in(const T *d, int N, const T *__restr
     out[r * K + k] = a;
   }
 }
-// dW[k*N + j] += sum_r in[r][k] d[r][j];  db[j] += sum_r d[r][j]   (atomics across workgroups)
+// dW[k*N + j] = sum_r in[r][k] d[r][j];  db[j] = sum_r d[r][j]   over this workgroup's samples, STORED in
+// the workgroup's own copy of the mid-layer gradients (elbo_finish_kernel sums the copies in order)
 template <typename T, int RB>
 __device__ __forceinline__ void dense_bwd_w(const T *in, int K, const T *d, int N, T *dW, T *db,
                                             int rows, int tid) {
@@ -71,10 +72,10 @@ __device__ __forceinline__ void dense_bwd_w(const T *in, int K, const T *d, int 
     if (k < K) {
 #pragma unroll 8
       for (int r = 0; r < rows; ++r) a += in[r * K + k] * d[r * N + j];
-      atomicAdd(&dW[(int64_t)k * N + j], a);
+      dW[(int64_t)k * N + j] = a;
     } else {
       for (int r = 0; r < rows; ++r) a += d[r * N + j];
-      atomicAdd(&db[j], a);
+      db[j] = a;
     }
   }
 }
@@ -127,40 +128,14 @@ static inline int64_t vae_param_count(int64_t n, int h0, int h1, int z) {
          (int64_t)h1 * h0 + h0 + (int64_t)h0 * n + n;
 }
 
-// workspace carve-up (elements of T)
-template <typename T> struct VaeWork {
-  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *MU, *LS, *REP, *DF;
-  // REP: GREP copies of the mid-layer gradients (small-MLP path): workgroup i adds into copy
-  // i % GREP, so an address sees B/16/GREP atomics instead of B/16 (same-address float atomics
-  // serialise at the memory side: 256 deep they were two thirds of vae_mid_bwd_kernel's time)
-  static constexpr int GREP = 16;
-  static int64_t rep_elems(int h0, int h1, int z) {
-    const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);
-    return mc <= 15360 ? GREP * mc : 0;  // only dims whose mid weights can be staged in LDS (60 KB)
-  }
-  static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
-    return B * (4 * (int64_t)h0 + 2 * (int64_t)h1 + 4 * (int64_t)z) + rep_elems(h0, h1, z) + B * n + 64;
-  }
-  // H1, dD2 and REP start from zero (split-K / replicated atomics): adjacent, one memset (zero_bytes)
-  int64_t zero_elems;
-  __host__ VaeWork(T *w, int64_t B, int64_t n, int h0, int h1, int z) {
-    H1 = w;            dD2 = H1 + B * h0;  REP = dD2 + B * h0;
-    zero_elems = 2 * B * h0 + rep_elems(h0, h1, z);
-    H2 = H1 + zero_elems;  SD = H2 + B * h1;   Z = SD + B * z;
-    D1 = Z + B * z;    D2 = D1 + B * h1;   dA1 = D2 + B * h0;
-    MU = dA1 + B * h0; LS = MU + B * z;  // wide-layer path only
-    DF = LS + B * z;
-    DF = (T *)(((uintptr_t)DF + 15) & ~(uintptr_t)15);
-  }
-};
-
 // encoder tail + reparametrisation + decoder head, RB samples per workgroup.
-// H1 holds Y W1 on entry (no bias) and relu(Y W1 + b1) on exit.
+// A1s holds Y W1 (no bias) as nsA k-slices slabA elements apart, summed here in slice order; H1 =
+// relu(Y W1 + b1) on exit.  The workgroup's latent loss terms go to lp[blockIdx.x].
 template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, const T *params,
-                                                               const T *eps, T *H1, T *H2, T *SD,
-                                                               T *Z, T *D1, T *D2, T *loss,
-                                                               T loss_const) {
+                                                               const T *eps, const T *A1s, int nsA,
+                                                               int64_t slabA, T *H1, T *H2, T *SD,
+                                                               T *Z, T *D1, T *D2, T *lp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *bufA = reinterpret_cast<T *>(smem_raw);  // [RB][max dim]
   const int mx = max(d.h0, max(d.h1, d.z));
@@ -179,7 +154,8 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     const int r = idx / h0, j = idx % h0;
     T v = T(0);
     if (r < rows) {
-      v = H1[(s0 + r) * h0 + j] + P.b1[j];
+      const int64_t e = (s0 + r) * h0 + j;
+      v = slab_sum_at<T>(A1s, nsA, slabA, e) + P.b1[j];
       v = v > T(0) ? v : T(0);
       H1[(s0 + r) * h0 + j] = v;
     }
@@ -231,23 +207,25 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_fwd_kernel(VaeDims<T> d, con
     const T v = bufC[idx] > T(0) ? bufC[idx] : T(0);
     if (r < rows) D2[(s0 + r) * h0 + idx % h0] = v;
   }
-  if (loss != nullptr) {
+  if (lp != nullptr) {
     lsum = wave_sum<T>(lsum);
     if ((tid & 63) == 0) red[tid >> 6] = lsum;
     __syncthreads();
-    if (tid == 0)
-      atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + (blockIdx.x == 0 ? loss_const : T(0)));
+    if (tid == 0) lp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
-// the same chain backwards.  dD2 holds DF V3^T on entry; dA1 (gradient at Y W1 + b1) on exit.
+// the same chain backwards.  dD2s holds DF V3^T as nsD partial sums slabD elements apart (summed here in
+// order); dA1 (gradient at Y W1 + b1) on exit; the mid-layer weight gradients of this workgroup's samples go
+// to its own copy rep[blockIdx.x].
 template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, const T *params,
                                                                T *grads, const T *eps,
                                                                const T *H1, const T *H2,
                                                                const T *SD, const T *Z,
                                                                const T *D1, const T *D2,
-                                                               const T *dD2, T *dA1, T *rep) {
+                                                               const T *dD2s, int nsD, int64_t slabD,
+                                                               T *dA1, T *rep) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int mx = max(d.h0, max(d.h1, d.z));
   T *act = reinterpret_cast<T *>(smem_raw);  // activations of the layer input
@@ -255,10 +233,8 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   T *gB = gA + RB * mx;
   T *gC = gB + RB * mx;
   VaeParams<T> P(params, d.n, d.h0, d.h1, d.z);
-  // the mid-layer gradients go to copy blockIdx.x % GREP of `rep` (vae_mid_reduce_kernel sums them)
   VaeParams<T> G(grads, d.n, d.h0, d.h1, d.z);  // same layout; const-cast below
-  G.relocate_mid(rep + (int64_t)(blockIdx.x % VaeWork<T>::GREP) * VaeParams<T>::mid_count(d.h0, d.h1, d.z),
-                 d.h0, d.h1, d.z);
+  G.relocate_mid(rep + (int64_t)blockIdx.x * VaeParams<T>::mid_count(d.h0, d.h1, d.z), d.h0, d.h1, d.z);
   const int tid = threadIdx.x;
   const int64_t s0 = (int64_t)blockIdx.x * RB;
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
@@ -269,7 +245,11 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   // dG2 = dD2 * (D2 > 0);  act = D1
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
     const int r = idx / h0, j = idx % h0;
-    gA[idx] = (ld(D2, r, h0, j) > T(0)) ? ld(dD2, r, h0, j) : T(0);
+    T g2 = T(0);
+    if (r < rows) {
+      g2 = slab_sum_at<T>(dD2s, nsD, slabD, (s0 + r) * h0 + j);
+    }
+    gA[idx] = (ld(D2, r, h0, j) > T(0)) ? g2 : T(0);
   }
   for (int idx = tid; idx < RB * h1; idx += NTHREADS) act[idx] = ld(D1, idx / h1, h1, idx % h1);
   __syncthreads();
@@ -314,16 +294,58 @@ __global__ __launch_bounds__(NTHREADS) void vae_mid_bwd_kernel(VaeDims<T> d, con
   }
 }
 
-// grads[n*h0 + i] = sum over the GREP copies, i in [h0, mid_count): everything of the mid run but b1
-// (whose gradient is the ones row of the dW1 product)
+// Last launch of an ELBO evaluation: every gradient that was left as partial sums is summed here in a
+// fixed order, and so is the loss — no floating-point atomics anywhere on the path, the same inputs give
+// the same bits.  The flat gradient vector is [W1 | b1] (nW1 elements, nsW k-slices of the dW1 product),
+// the rest of the mid run (nmid elements, nrep per-workgroup copies of mc elements; nrep == 0: written
+// elsewhere, skipped) and [V3 | c3] (nV3 elements, nsV partial sums).  Block 0 also sums the nlp loss parts.
 template <typename T>
-__global__ void vae_mid_reduce_kernel(int64_t mc, int h0, const T *__restrict__ rep, T *gmid) {
-  const int64_t i = h0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= mc) return;
+__global__ __launch_bounds__(256) void elbo_finish_kernel(T *grads, int64_t nW1, const T *__restrict__ SW1, int nsW,
+                                                          int64_t slabW, int h0, int64_t mc,
+                                                          const T *__restrict__ REP, int64_t nrep, int64_t nV3,
+                                                          const T *__restrict__ SV3, int nsV, int64_t slabV,
+                                                          T *loss, const T *__restrict__ LP, int64_t nlp,
+                                                          T loss_const, int blocks_a) {
+  __shared__ T red[256];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < blocks_a) {
+    // [W1 | b1] and [V3 | c3]: one output per thread and pass, a few tens of slabs each
+    if (grads != nullptr) {
+      const int64_t nmid = mc - h0;
+      for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < nW1 + nV3; i += (int64_t)blocks_a * 256) {
+        if (i < nW1) grads[i] = slab_sum_at<T>(SW1, nsW, slabW, i);
+        else grads[i + nmid] = slab_sum_at<T>(SV3, nsV, slabV, i - nW1);
+      }
+    }
+    if (blockIdx.x == 0 && loss != nullptr) {
+      T a = T(0);
+      for (int64_t i = tid; i < nlp; i += 256) a += LP[i];
+      red[tid] = a;
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+      }
+      if (tid == 0) loss[0] = red[0] + loss_const;
+    }
+    return;
+  }
+  // mid run: few outputs, one copy per workgroup of vae_mid_bwd_kernel (hundreds): 16 outputs per block,
+  // 16 threads per output, each adding its contiguous share of the copies in order, then the 16 shares in order
+  const int64_t j = h0 + ((int64_t)blockIdx.x - blocks_a) * 16 + (tid & 15);
+  const int c = tid >> 4;
+  const int64_t per = (nrep + 15) / 16;
+  const int64_t r0 = c * per, r1 = (r0 + per < nrep) ? r0 + per : nrep;
   T a = T(0);
+  if (j < mc && r0 < r1) a = slab_sum_at<T>(REP + r0 * mc, (int)(r1 - r0), mc, j);
+  red[tid] = a;
+  __syncthreads();
+  if (c == 0 && j < mc) {
+    T v = red[tid];
 #pragma unroll
-  for (int r = 0; r < VaeWork<T>::GREP; ++r) a += rep[r * mc + i];
-  gmid[i] = a;
+    for (int k = 1; k < 16; ++k) v += red[k * 16 + tid];
+    grads[nW1 + (j - h0)] = v;
+  }
 }
 
 // decoder head only (chains): Z -> D1 -> D2 (a11 forward), and its reverse (a11 VJP)
@@ -412,7 +434,7 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void reparam_kernel(int64_t count, const T *__restrict__ MU,
                                                            const T *__restrict__ LS,
                                                            const T *__restrict__ eps, T *SD, T *Z,
-                                                           T *loss, T loss_const) {
+                                                           T *lp) {
   __shared__ T red[4];
   T lsum = T(0);
   for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < count;
@@ -427,8 +449,7 @@ __global__ __launch_bounds__(NTHREADS) void reparam_kernel(int64_t count, const 
   lsum = wave_sum<T>(lsum);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
   __syncthreads();
-  if (threadIdx.x == 0)
-    atomicAdd(loss, red[0] + red[1] + red[2] + red[3] + (blockIdx.x == 0 ? loss_const : T(0)));
+  if (threadIdx.x == 0) lp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // on entry MU holds dZ (decoder part); on exit MU = dmu = dZ + z, LS = dls = dmu eps sd - 1
 template <typename T>
@@ -441,17 +462,6 @@ __global__ void latent_grad_kernel(int64_t count, T *MU, T *LS, const T *__restr
     LS[i] = dmu * eps[i] * SD[i] - T(1);
   }
 }
-// one launch clears what an ELBO evaluation accumulates into (loss word, split-K / replica buffers,
-// gradient vector): three hipMemsetAsync calls were three ~5 us launches on the step's critical path
-__global__ void zero3_kernel(uint32_t *a, int64_t na, uint32_t *b, int64_t nb, uint32_t *c, int64_t nc) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += stride) {
-    if (i < na) a[i] = 0u;
-    else if (i < na + nb) b[i - na] = 0u;
-    else c[i - na - nb] = 0u;
-  }
-}
-
 static inline unsigned ew_blocks(int64_t count) {
   const int64_t b = cdiv(count, (int64_t)NTHREADS * 4);
   return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -462,6 +472,9 @@ static inline unsigned ew_blocks(int64_t count) {
 //   F   = [D2 | 1] [V3; c3]                     DF = (F - Y) / sigma^2 ,  loss += 0.5 sum (F - Y)^2 / sigma^2
 //   dD2 += DF V3^T                              (per 64-column tile: K = the tile's columns)
 //   [dV3; dc3] += [D2 | 1]^T DF                 (per 128-row block: K = the block's rows)
+// Sums across workgroups are left as partial sums in slabs (no float atomics): row block bx stores its
+// [dV3; dc3] tiles in slab bx of dV3s, column group by its dD2 rows in slab by of dD2s and its share of the
+// loss in lp[by * gridDim.x + bx]; vae_mid_bwd_kernel / elbo_finish_kernel add the slabs in order.
 // As separate launches DF (B x n) is written once and read twice (3 x 67 MB at C3).  Here a workgroup
 // keeps its 128 rows of [D2 | 1] in LDS and walks `nt` column tiles: product 1 from LDS, the
 // epilogue leaves the DF tile in LDS, and that tile is the A operand of product 2 (row-major image)
@@ -472,8 +485,8 @@ constexpr int FS = 68;  // LDS row stride of the 64-wide images (16-byte aligned
 
 __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
     int64_t n, int h0, const float *__restrict__ D2, const float *__restrict__ V3c,
-    const float *__restrict__ Y, int64_t ldy, float inv_var, float *loss, float *dD2, float *dV3c,
-    int nt) {
+    const float *__restrict__ Y, int64_t ldy, float inv_var, float *lp, float *dD2s, int64_t slabD,
+    float *dV3s, int64_t slabV, int nt) {
   using M = Mfma<float>;
   // 153 KB of LDS, one workgroup per CU.  The V3 image is triple- and the DF image double-buffered, so
   // that ONE barrier per tile (DF tile complete / next V3 tile staged) orders everything and product 1
@@ -517,8 +530,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
     }
   };
   // data tile of this wave's 32 rows; like the V3 tile it is requested ahead and BEFORE the previous
-  // tile's atomics: loads return in order, a load issued behind 16 float atomics would not be counted
-  // done until they have all been (about 3 k cycles with every CU adding at once)
+  // tile's gradient stores
   float yv[2][M::NACC];
   auto load_y = [&](int64_t tile) {
     TileIO<float> ioy;
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
         lsum += diff * diff;
         DFs[(wave * 32 + M::row(lane, r)) * FS + fn * 32 + M::col(lane)] = diff * inv_var;
       }
-    if (t + 1 < ntl) {  // next tile's operands, ahead of this tile's atomics
+    if (t + 1 < ntl) {  // next tile's operands, ahead of this tile's gradient stores
       stage_v3(V3b + ((t + 1) % 3) * 64 * FS);
       load_y(tile0 + t + 1);
       if (t + 2 < ntl) load_v3(tile0 + t + 2);
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
 #pragma unroll
     for (int r = 0; r < M::NACC; ++r) {
       const int hi = wm3 + M::row(lane, r);
-      if (hi <= h0) atomicAdd(&dV3c[(int64_t)hi * n + col0 + wn3 + M::col(lane)], acc3[0][0][r]);
+      if (hi <= h0) dV3s[(int64_t)blockIdx.x * slabV + (int64_t)hi * n + col0 + wn3 + M::col(lane)] = acc3[0][0][r];
     }
   }
 #pragma unroll
@@ -575,13 +587,13 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
 #pragma unroll
     for (int r = 0; r < M::NACC; ++r) {
       const int hi = fn * 32 + M::col(lane);
-      if (hi < h0) atomicAdd(&dD2[(row0 + wave * 32 + M::row(lane, r)) * h0 + hi], acc2[0][fn][r]);
+      if (hi < h0) dD2s[(int64_t)blockIdx.y * slabD + (row0 + wave * 32 + M::row(lane, r)) * h0 + hi] = acc2[0][fn][r];
     }
   __shared__ float red[4];
   lsum = wave_sum<float>(lsum);
   if (lane == 0) red[wave] = lsum;
   __syncthreads();
-  if (tid == 0) atomicAdd(loss, 0.5f * inv_var * (red[0] + red[1] + red[2] + red[3]));
+  if (tid == 0) lp[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5f * inv_var * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ---- Adam (jax.experimental.optimizers.adam, as numpyro.optim.Adam wraps it) ------------------------
@@ -641,14 +653,18 @@ static void dense_gemm_t(hipStream_t st, const T *G, int64_t M, int N, const T *
   g.vec_a = kc_vec_ok<T>(G, N); g.vec_b = kc_vec_ok<T>(W, N);
   launch_gemm<T, true, true, EPI_FUSED>(st, g, 1);
 }
-// [dW; db] += [A | 1]^T G      ((K+1) x N, summed over the M samples; W and b adjacent in the layout)
+// [dW; db] = [A | 1]^T G      ((K+1) x N, summed over the M samples; W and b adjacent in the layout):
+// k-slices into `slabs`, then summed in slice order into dW
+static inline int gemm_w_splits(int K, int N, int64_t M) { return pick_splitk(cdiv(K + 1, GBM) * cdiv(N, GBN), M); }
 template <typename T>
-static void dense_gemm_w(hipStream_t st, const T *A, int64_t M, int K, const T *G, int N, T *dW) {
+static void dense_gemm_w(hipStream_t st, const T *A, int64_t M, int K, const T *G, int N, T *dW, T *slabs) {
   GemmArgs<T> g{};
-  g.A = A; g.lda = K; g.B = G; g.ldb = N; g.C = dW; g.ldc = N;
+  g.A = A; g.lda = K; g.B = G; g.ldb = N; g.C = slabs; g.ldc = N;
   g.M = K + 1; g.N = N; g.K = M; g.a_ones_row = K;
+  g.slab = (int64_t)(K + 1) * N;
   g.vec_a = mc_vec_ok<T>(A, K); g.vec_b = mc_vec_ok<T>(G, N);
-  launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(K + 1, GBM) * cdiv(N, GBN), M));
+  const int ns = launch_gemm<T, false, false, EPI_ATOMIC>(st, g, gemm_w_splits(K, N, M));
+  launch_slab_sum<T>(st, dW, slabs, g.slab, ns, g.slab);
 }
 
 // samples per workgroup of the mid kernels: the backward kernel keeps four [RB][mx] buffers in LDS and a
@@ -666,136 +682,227 @@ template <typename T> static inline int pick_rb(int mx, int nbuf) {
     default: { constexpr int RB = 2;  __VA_ARGS__; } break;        \
   }
 
+// Shapes of one ELBO evaluation: which path runs, how every cross-workgroup sum is split, and how much slab
+// space that takes.  gpvae_vae_workspace_bytes and run_vae_elbo both read it, so they cannot disagree.
+template <typename T> struct ElboPlan {
+  int rb;
+  bool wide;
+  int64_t nblk, mc;
+  bool fused_dims;   // the shapes allow vae_out_fused_kernel (it also needs gradients and a 2 GiB-safe ldy)
+  int nt;            // column tiles per workgroup of the fused kernel
+  int64_t fgx, fgy;  // its grid: row blocks x column groups
+  int sA1, sW1, sV3, sD2;  // k-slices of the four n-sized split products (sV3, sD2: the unfused path)
+  int64_t nsV3, nsD2;      // slabs reserved = the larger of the fused and the unfused need
+  int64_t nlp_mid, nlp;    // loss parts: mid / reparam kernel, then the output layer's workgroups
+  int64_t tmp_elems;       // wide path: slabs of one mid-layer weight-gradient product at a time
+  int64_t rep_elems;       // small path: one copy of the mid-layer gradients per workgroup
+  ElboPlan(int64_t B, int64_t n, int h0, int h1, int z) {
+    const int mx = std::max(h0, std::max(h1, z));
+    mc = VaeParams<T>::mid_count(h0, h1, z);
+    const size_t mid_bytes = (size_t)mc * sizeof(T);
+    rb = pick_rb<T>(mx, 4);
+    wide = rb == 0 || mid_bytes + 4 * (size_t)rb * mx * sizeof(T) > 60 * 1024;
+    nblk = cdiv(B, rb > 0 ? rb : 1);
+    fused_dims = sizeof(T) == 4 && h0 + 1 <= 64 && B % 128 == 0 && n % 64 == 0 &&
+                 (int64_t)(h0 + 1) * n * 4 < ((int64_t)1 << 31);
+    const int64_t rb128 = B / 128, ntiles = n / 64;
+    nt = (int)(rb128 * ntiles / 256);  // about 256 workgroups: one per CU (153 KB of LDS each) in one round
+    if (nt < 1) nt = 1;
+    fgx = rb128;
+    fgy = cdiv(ntiles, nt);
+    sA1 = gemm_slices<T>(n, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+    sW1 = gemm_slices<T>(B, pick_splitk(cdiv(n + 1, 64) * cdiv(h0, GBN), B, 1024));
+    sV3 = gemm_slices<T>(B, h0 + 1 <= 64 ? pick_splitk(cdiv(n, GBN), B)
+                                          : pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
+    sD2 = gemm_slices<T>(n, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+    nsV3 = std::max<int64_t>(sV3, fused_dims ? fgx : 0);
+    nsD2 = std::max<int64_t>(sD2, fused_dims ? fgy : 0);
+    nlp_mid = wide ? 2048 : nblk;
+    nlp = nlp_mid + std::max<int64_t>(cdiv(B, GBM) * cdiv(n, GBN), fused_dims ? fgx * fgy : 0);
+    tmp_elems = 0;
+    if (wide) {
+      const int kk[5] = {h1, z, h1, h1, h0}, nn[5] = {h0, h1, z, z, h1};
+      for (int i = 0; i < 5; ++i)
+        tmp_elems = std::max<int64_t>(tmp_elems, (int64_t)gemm_slices<T>(B, gemm_w_splits(kk[i], nn[i], B)) * (kk[i] + 1) * nn[i]);
+    }
+    rep_elems = wide ? 0 : nblk * mc;
+  }
+  int64_t slab_elems(int64_t B, int64_t n, int h0) const {
+    return sA1 * B * h0 + nsD2 * B * h0 + nsV3 * (int64_t)(h0 + 1) * n + sW1 * (n + 1) * h0 + rep_elems + tmp_elems +
+           nlp + 64;
+  }
+};
+
+// workspace carve-up (elements of T)
+template <typename T> struct VaeWork {
+  T *H1, *H2, *SD, *Z, *D1, *D2, *dD2, *dA1, *MU, *LS, *DF;
+  T *SA1, *SD2, *SV3, *SW1, *REP, *TMP, *LP;  // partial sums (ElboPlan): nothing here needs clearing
+  static int64_t elems(int64_t B, int64_t n, int h0, int h1, int z) {
+    const ElboPlan<T> p(B, n, h0, h1, z);
+    return B * (4 * (int64_t)h0 + 2 * (int64_t)h1 + 4 * (int64_t)z) + p.slab_elems(B, n, h0) + B * n + 64;
+  }
+  __host__ VaeWork(T *w, const ElboPlan<T> &p, int64_t B, int64_t n, int h0, int h1, int z) {
+    H1 = w;            dD2 = H1 + B * h0;
+    H2 = dD2 + B * h0; SD = H2 + B * h1;   Z = SD + B * z;
+    D1 = Z + B * z;    D2 = D1 + B * h1;   dA1 = D2 + B * h0;
+    MU = dA1 + B * h0; LS = MU + B * z;  // wide-layer path only
+    SA1 = LS + B * z;  SD2 = SA1 + p.sA1 * B * h0;  SV3 = SD2 + p.nsD2 * B * h0;
+    SW1 = SV3 + p.nsV3 * (int64_t)(h0 + 1) * n;     REP = SW1 + p.sW1 * (n + 1) * h0;
+    TMP = REP + p.rep_elems;  LP = TMP + p.tmp_elems;
+    DF = LP + p.nlp;
+    DF = (T *)(((uintptr_t)DF + 15) & ~(uintptr_t)15);
+  }
+};
+
 template <typename T>
 static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, int z,
                         const void *params_v, const void *Y_v, int64_t ldy, const void *eps_v,
                         double obs_sigma, void *loss_v, void *grads_v, void *work_v) {
   const T *params = (const T *)params_v, *Y = (const T *)Y_v, *eps = (const T *)eps_v;
   T *loss = (T *)loss_v, *grads = (T *)grads_v;
-  VaeWork<T> W((T *)work_v, B, n, h0, h1, z);
+  const ElboPlan<T> pl(B, n, h0, h1, z);
+  VaeWork<T> W((T *)work_v, pl, B, n, h0, h1, z);
   VaeParams<T> P(params, n, h0, h1, z);
   VaeDims<T> dims{B, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
   // Small hidden layers (the reference's 35-30-10 / 50-30-15): the whole chain between the two n-sized
   // layers runs per block of samples with its weights staged in LDS.  When weights + activation
   // buffers do not fit the 64 KB a launch may ask for, every layer is a tile product instead.
-  const size_t mid_bytes = (size_t)VaeParams<T>::mid_count(h0, h1, z) * sizeof(T);
-  const int rb = pick_rb<T>(mx, 4);
-  const bool wide = rb == 0 || mid_bytes + 4 * (size_t)rb * mx * sizeof(T) > 60 * 1024;
+  // Every sum across workgroups (split K, per-sample-block weight gradients, the loss) is left as partial
+  // sums in slabs of the workspace and added in a fixed order by its consumer or by elbo_finish_kernel:
+  // no floating-point atomics, the same inputs give the same bits, and nothing needs clearing first.
+  const int rb = pl.rb;
+  const bool wide = pl.wide;
+  const size_t mid_bytes = (size_t)pl.mc * sizeof(T);
   const size_t shm_f = 3 * (size_t)rb * mx * sizeof(T) + mid_bytes;
   const size_t shm_b = 4 * (size_t)rb * mx * sizeof(T) + mid_bytes;
-  const unsigned nblk = (unsigned)cdiv(B, rb > 0 ? rb : 1);
+  const unsigned nblk = (unsigned)pl.nblk;
   const int64_t Bz = B * z;
   const T inv_var = (T)(1.0 / (obs_sigma * obs_sigma));
   // constant of the data term: B*n*(log sigma + 0.5 log 2pi)
   const T loss_const = (T)((double)B * (double)n * (log(obs_sigma) + 0.9189385332046727));
+  const int64_t slabH = B * h0;  // slab of a (B x h0) partial sum
+  int64_t nlp = 0;               // loss parts written so far
 
-  {
-    constexpr int64_t WPE = sizeof(T) / 4;  // 32-bit words per element
-    const int64_t nh = WPE * (grads != nullptr ? W.zero_elems : B * h0);
-    const int64_t ng = grads != nullptr ? WPE * vae_param_count(n, h0, h1, z) : 0;
-    int64_t blocks = cdiv(WPE + nh + ng, 256 * 4);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(zero3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)loss, WPE,
-                       (uint32_t *)W.H1, nh, (uint32_t *)grads, ng);
-  }
-  {  // A1 += Y W1
+  int nsA;
+  {  // A1 = Y W1, as k-slices
     GemmArgs<T> g{};
-    g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.H1; g.ldc = h0;
+    g.A = Y; g.lda = ldy; g.B = P.W1; g.ldb = h0; g.C = W.SA1; g.ldc = h0; g.slab = slabH;
     g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
     g.vec_a = kc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(P.W1, h0);
-    launch_gemm<T, true, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+    nsA = launch_gemm<T, true, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
   }
   if (!wide) {
     GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_fwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm_f,
-                                           st, dims, params, eps, W.H1, W.H2, W.SD, W.Z, W.D1, W.D2, loss,
-                                           loss_const));
+                                           st, dims, params, eps, (const T *)W.SA1, nsA, slabH, W.H1, W.H2,
+                                           W.SD, W.Z, W.D1, W.D2, W.LP));
+    nlp = nblk;
   } else {
+    launch_slab_sum<T>(st, W.H1, W.SA1, slabH, nsA, slabH);
     hipLaunchKernelGGL((bias_relu_kernel<T>), dim3(ew_blocks(B * h0)), dim3(NTHREADS), 0, st, B * h0, h0,
                        W.H1, P.b1);
     dense_gemm<T>(st, W.H1, B, h0, P.W2, h1, P.b2, 1, W.H2);
     dense_gemm<T>(st, W.H2, B, h1, P.Wmu, z, P.bmu, 0, W.MU);
     dense_gemm<T>(st, W.H2, B, h1, P.Wsd, z, P.bsd, 0, W.LS);
-    hipLaunchKernelGGL((reparam_kernel<T>), dim3(ew_blocks(Bz)), dim3(NTHREADS), 0, st, Bz, W.MU, W.LS, eps,
-                       W.SD, W.Z, loss, loss_const);
+    const unsigned rblocks = ew_blocks(Bz);
+    hipLaunchKernelGGL((reparam_kernel<T>), dim3(rblocks), dim3(NTHREADS), 0, st, Bz, W.MU, W.LS, eps,
+                       W.SD, W.Z, W.LP);
+    nlp = rblocks;
     dense_gemm<T>(st, W.Z, B, z, P.V1, h1, P.c1, 1, W.D1);
     dense_gemm<T>(st, W.D1, B, h1, P.V2, h0, P.c2, 1, W.D2);
   }
   // f32 with gradients, whole tiles: the output layer's three n-sized products in one pass
+  const int64_t slabV = (int64_t)(h0 + 1) * n;
+  int nsV = 0, nsD = 0;
   bool fused = false;
-  if constexpr (sizeof(T) == 4) {
-    fused = grads != nullptr && h0 + 1 <= 64 && B % 128 == 0 && n % 64 == 0 &&
-            (int64_t)(h0 + 1) * n * 4 < ((int64_t)1 << 31) && 32 * ldy * 4 < ((int64_t)1 << 31);
-  }
+  if constexpr (sizeof(T) == 4) fused = grads != nullptr && pl.fused_dims && 32 * ldy * 4 < ((int64_t)1 << 31);
   if (fused) {
     if constexpr (sizeof(T) == 4) {
-      VaeParams<T> G(grads, n, h0, h1, z);
-      const int64_t rb128 = B / 128, ntiles = n / 64;
-      int nt = (int)(rb128 * ntiles / 256);  // about 256 workgroups: one per CU (87 KB of LDS each) in one round
-      if (nt < 1) nt = 1;
-      hipLaunchKernelGGL(vae_out_fused_kernel, dim3((unsigned)rb128, (unsigned)cdiv(ntiles, nt)), dim3(NTHREADS),
-                         0, st, n, h0, W.D2, P.V3, Y, ldy, inv_var, loss, W.dD2, (T *)G.V3, nt);
+      hipLaunchKernelGGL(vae_out_fused_kernel, dim3((unsigned)pl.fgx, (unsigned)pl.fgy), dim3(NTHREADS), 0, st, n,
+                         h0, W.D2, P.V3, Y, ldy, inv_var, W.LP + nlp, W.SD2, slabH, W.SV3, slabV, pl.nt);
+      nlp += pl.fgx * pl.fgy;
+      nsV = (int)pl.fgx;
+      nsD = (int)pl.fgy;
     }
-  } else {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss += 0.5 sum diff^2 / sigma^2
+  } else {  // DF = (D2 V3 + c3 - Y)/sigma^2 ; loss parts 0.5 sum diff^2 / sigma^2
     GemmArgs<T> g{};
     g.A = W.D2; g.lda = h0; g.B = P.V3; g.ldb = n; g.C = W.DF; g.ldc = n;
     g.M = B; g.N = n; g.K = h0; g.a_ones_row = -1;
-    g.bias = P.c3; g.Yref = Y; g.ldy = ldy; g.inv_var = inv_var; g.loss = loss;
+    g.bias = P.c3; g.Yref = Y; g.ldy = ldy; g.inv_var = inv_var; g.loss = loss; g.loss_part = W.LP + nlp;
     g.vec_a = kc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(P.V3, n);
     launch_gemm<T, true, false, EPI_DF>(st, g, 1);
+    nlp += cdiv(B, GBM) * cdiv(n, GBN);
   }
+  int nsW = 0;
   if (grads != nullptr) {
     VaeParams<T> G(grads, n, h0, h1, z);
     if (!fused) {
-      {  // [dV3; dc3] += [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
+      {  // [dV3; dc3] = [D2 | 1]^T DF        ((h0+1) x n; V3 and c3 are adjacent in the layout)
         GemmArgs<T> g{};
-        g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = (T *)G.V3; g.ldc = n;
+        g.A = W.D2; g.lda = h0; g.B = W.DF; g.ldb = n; g.C = W.SV3; g.ldc = n; g.slab = slabV;
         g.M = h0 + 1; g.N = n; g.K = B; g.a_ones_row = h0;
         g.vec_a = mc_vec_ok<T>(W.D2, h0); g.vec_b = mc_vec_ok<T>(W.DF, n);
         if (h0 + 1 <= 64)
-          launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n, GBN), B));
+          nsV = launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n, GBN), B));
         else
-          launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
+          nsV = launch_gemm<T, false, false, EPI_ATOMIC>(st, g, pick_splitk(cdiv(h0 + 1, GBM) * cdiv(n, GBN), B));
       }
-      {  // dD2 += DF V3^T
+      {  // dD2 = DF V3^T
         GemmArgs<T> g{};
-        g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.dD2; g.ldc = h0;
+        g.A = W.DF; g.lda = n; g.B = P.V3; g.ldb = n; g.C = W.SD2; g.ldc = h0; g.slab = slabH;
         g.M = B; g.N = h0; g.K = n; g.a_ones_row = -1;
         g.vec_a = kc_vec_ok<T>(W.DF, n); g.vec_b = kc_vec_ok<T>(P.V3, n);
-        launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
+        nsD = launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(B, 64) * cdiv(h0, GBN), n, 1024));
       }
     }
+    if (nsV > pl.nsV3 || nsD > pl.nsD2 || nsA > pl.sA1 || nlp > pl.nlp) {
+      set_error("gpvae_vae_elbo: internal: slab plan exceeded");
+      return -14;
+    }
     if (!wide) {
-      const int64_t mc = VaeParams<T>::mid_count(h0, h1, z);
       GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((vae_mid_bwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS),
                                              shm_b, st, dims, params, grads, eps, W.H1, W.H2, W.SD, W.Z,
-                                             W.D1, W.D2, W.dD2, W.dA1, W.REP));
-      hipLaunchKernelGGL((vae_mid_reduce_kernel<T>), dim3((unsigned)cdiv(mc - h0, 256)), dim3(256), 0, st,
-                         mc, h0, W.REP, grads + n * h0);
+                                             W.D1, W.D2, (const T *)W.SD2, nsD, slabH, W.dA1, W.REP));
     } else {
       // gradient buffers reuse the activations they mask: dG2 in dD2, dG1 then dA2 in D1, dmu | dls in MU | LS
+      launch_slab_sum<T>(st, W.dD2, W.SD2, slabH, nsD, slabH);
       hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(B * h0)), dim3(NTHREADS), 0, st, B * h0,
                          W.dD2, W.D2);                                      // dG2
-      dense_gemm_w<T>(st, W.D1, B, h1, W.dD2, h0, (T *)G.V2);              // dV2 | dc2
+      dense_gemm_w<T>(st, W.D1, B, h1, W.dD2, h0, (T *)G.V2, W.TMP);       // dV2 | dc2
       dense_gemm_t<T>(st, W.dD2, B, h0, P.V2, h1, W.D1, 0, W.D1);          // dG1 = (dG2 V2^T) (D1 > 0)
-      dense_gemm_w<T>(st, W.Z, B, z, W.D1, h1, (T *)G.V1);                 // dV1 | dc1
+      dense_gemm_w<T>(st, W.Z, B, z, W.D1, h1, (T *)G.V1, W.TMP);          // dV1 | dc1
       dense_gemm_t<T>(st, W.D1, B, h1, P.V1, z, W.MU, 0, (const T *)nullptr);  // dZ (decoder part)
       hipLaunchKernelGGL((latent_grad_kernel<T>), dim3(ew_blocks(Bz)), dim3(NTHREADS), 0, st, Bz, W.MU, W.LS,
                          eps, W.SD, W.Z);
-      dense_gemm_w<T>(st, W.H2, B, h1, W.MU, z, (T *)G.Wmu);               // dWmu | dbmu
-      dense_gemm_w<T>(st, W.H2, B, h1, W.LS, z, (T *)G.Wsd);               // dWsd | dbsd
+      dense_gemm_w<T>(st, W.H2, B, h1, W.MU, z, (T *)G.Wmu, W.TMP);        // dWmu | dbmu
+      dense_gemm_w<T>(st, W.H2, B, h1, W.LS, z, (T *)G.Wsd, W.TMP);        // dWsd | dbsd
       dense_gemm_t<T>(st, W.MU, B, z, P.Wmu, h1, W.D1, 0, (const T *)nullptr);
       dense_gemm_t<T>(st, W.LS, B, z, P.Wsd, h1, W.D1, 1, W.H2);           // dA2 = (dmu Wmu^T + dls Wsd^T) (H2 > 0)
-      dense_gemm_w<T>(st, W.H1, B, h0, W.D1, h1, (T *)G.W2);               // dW2 | db2
+      dense_gemm_w<T>(st, W.H1, B, h0, W.D1, h1, (T *)G.W2, W.TMP);        // dW2 | db2
       dense_gemm_t<T>(st, W.D1, B, h1, P.W2, h0, W.dA1, 0, W.H1);          // dA1 = (dA2 W2^T) (H1 > 0)
     }
-    {  // [dW1; db1] += [Y | 1]^T dA1        ((n+1) x h0; W1 and b1 are adjacent in the layout)
+    {  // [dW1; db1] = [Y | 1]^T dA1        ((n+1) x h0; W1 and b1 are adjacent in the layout)
       GemmArgs<T> g{};
-      g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = (T *)G.W1; g.ldc = h0;
+      g.A = Y; g.lda = ldy; g.B = W.dA1; g.ldb = h0; g.C = W.SW1; g.ldc = h0; g.slab = (n + 1) * h0;
       g.M = n + 1; g.N = h0; g.K = B; g.a_ones_row = n;
       g.vec_a = mc_vec_ok<T>(Y, ldy); g.vec_b = mc_vec_ok<T>(W.dA1, h0);
-      launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n + 1, 64) * cdiv(h0, GBN), B, 1024));
+      nsW = launch_gemm<T, false, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(n + 1, 64) * cdiv(h0, GBN), B, 1024));
+      if (nsW > pl.sW1) {
+        set_error("gpvae_vae_elbo: internal: slab plan exceeded");
+        return -14;
+      }
     }
+  }
+  {  // gradients and loss from their parts, in order
+    const int64_t nW1 = (n + 1) * h0;
+    int64_t blocks_a = grads != nullptr ? cdiv(nW1 + slabV, 256 * 2) : 1;
+    if (blocks_a < 1) blocks_a = 1;
+    if (blocks_a > 4096) blocks_a = 4096;
+    const int64_t nrep = (grads != nullptr && !wide) ? (int64_t)nblk : 0;
+    const int64_t blocks_b = nrep > 0 ? cdiv(pl.mc - h0, 16) : 0;
+    hipLaunchKernelGGL((elbo_finish_kernel<T>), dim3((unsigned)(blocks_a + blocks_b)), dim3(256), 0, st, grads, nW1,
+                       (const T *)W.SW1, nsW, nW1, h0, pl.mc, (const T *)W.REP, nrep, slabV,
+                       (const T *)W.SV3, nsV, slabV, loss, (const T *)W.LP, nlp, loss_const, (int)blocks_a);
   }
   GPVAE_CHECK_LAUNCH("gpvae_vae_elbo");
   return 0;
@@ -994,7 +1101,7 @@ extern "C" int64_t gpvae_vae_param_count(int64_t n, int h0, int h1, int z) {
 extern "C" int64_t gpvae_vae_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1,
                                              int z) {
   const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
-  return VaeWork<float>::elems(B, n, h0, h1, z) * es + 256;
+  return (dtype == GPVAE_F64 ? VaeWork<double>::elems(B, n, h0, h1, z) : VaeWork<float>::elems(B, n, h0, h1, z)) * es + 256;
 }
 
 extern "C" int gpvae_vae_elbo(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,

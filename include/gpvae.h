@@ -237,7 +237,10 @@ int gpvae_gp_potential(void *stream, int dtype, int d, int64_t n, int chains, co
  *                       V1[z,h1] c1[h1] V2[h1,h0] c2[h0] V3[h0,n] c3[n]
  * (gpvae_vae_param_count gives the length).  Y: [B, ldy] data, eps_z: [B, z] standard normals.
  * loss: device scalar (overwritten).  grads: flat array like params (overwritten) or NULL for a
- * forward-only evaluation (svi.evaluate, vae.py:194).  work: gpvae_vae_workspace_bytes() bytes.   */
+ * forward-only evaluation (svi.evaluate, vae.py:194).  work: gpvae_vae_workspace_bytes() bytes; its
+ * contents on entry do not matter.  Reproducible: every sum across workgroups (split-K products, weight
+ * gradients over the batch, the loss) is kept as partial sums in `work` and added in a fixed order —
+ * no floating-point atomics — so the same inputs give the same bits on every call.                 */
 int64_t gpvae_vae_param_count(int64_t n, int h0, int h1, int z);
 int64_t gpvae_vae_workspace_bytes(int dtype, int64_t B, int64_t n, int h0, int h1, int z);
 int gpvae_vae_elbo(void *stream, int dtype, int64_t B, int64_t n, int h0, int h1, int z,

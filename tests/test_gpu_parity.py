@@ -652,6 +652,32 @@ def test_vae_fused_output_layer(ops, dims):
         assert rel(gd[k], go[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dims", [(256, 256, 50, 30, 15), (100, 300, 35, 30, 10), (128, 256, 512, 256, 64), (512, 1088, 50, 30, 15)])
+def test_vae_elbo_is_bitwise_reproducible(ops, tdt, dims):
+    """gpvae_vae_elbo sums across workgroups in a fixed order (slabs of partial sums, no floating-point
+    atomics): two evaluations of the same inputs give the same bits — loss and all 14 gradient arrays — on
+    the fused, unfused and wide-layer paths, and whatever the workspace held before (nothing in it needs
+    clearing: it is handed over full of NaN)."""
+    B, n, h0, h1, z = dims
+    rng = np.random.default_rng(21)
+    p = {k: (5 * v) for k, v in orc.init_params(rng, n, h0, h1, z, np.float64).items()}
+    flat = dev(orc.flatten(p), tdt)
+    Y, ez = dev(rng.standard_normal((B, n)), tdt), dev(rng.standard_normal((B, z)), tdt)
+    out = []
+    for fill in (float("nan"), 1.0e30):
+        work = ops.VaeWorkspace(B, n, h0, h1, z, tdt, DEV)
+        work.buf.view(torch.float32)[:] = fill
+        grads = torch.full_like(flat, fill)
+        loss = ops.vae_elbo(flat, Y, ez, (h0, h1, z), 0.1, grads=grads, work=work)
+        ev = ops.vae_elbo(flat, Y, ez, (h0, h1, z), 0.1, work=work)  # evaluate-only on the used workspace
+        out.append((loss.clone(), grads, ev.clone()))
+    assert torch.isfinite(out[0][1]).all() and torch.isfinite(out[0][0]).all()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    lo, _ = orc.elbo_loss_and_grads(p, Y.double().cpu().numpy(), ez.double().cpu().numpy(), 0.1)
+    assert abs(out[0][0].item() - lo) < (1e-10 if tdt == torch.float64 else 1e-4) * abs(lo)
+
+
 def test_vae_elbo_full_size_c3(ops):
     """The bench shape (B = n = 4096, 50-30-15, fp32) against the oracle: every fast path of the tile
     products (VALU-free k loops, ragged-K through the buffer range check, TileIO epilogues, split-K
