@@ -332,6 +332,28 @@ class StepEngine():
         self.ev_free = [torch.cuda.Event() for _ in range(2)]    # group slot s has been consumed
         self.ev_copied = [torch.cuda.Event() for _ in range(2)]  # slot s's hyper upload is done
         self.draw_events = None  # bench.py: list of (start, end) HIP events around gpvae_draw
+        # The small configurations (C1, C2) are bound by the host's launch rate, so the per-step path below
+        # makes no tensor views and no wrapper calls: raw device pointers are taken once here, the library is
+        # called with explicit stream handles (no stream context switches), six ABI calls per step
+        self._lib = _lib.load()
+        self._dtc = _dt(self.x)
+        es = self.x.element_size()
+        vp = C.c_void_p
+        self._pK = [[vp(self.Kbuf[s].data_ptr() + i * n * self.ld * es) for i in range(G)] for s in range(2)]
+        self._psig = [[vp(self.hyper_dev[s].data_ptr() + (2 * G + i) * es) for i in range(G)] for s in range(2)]
+        if self.b3:
+            self._pL3 = [[vp(self.L3buf[s].data_ptr() + i * 3 * n * n * 2) for i in range(G)] for s in range(2)]
+            self._pE3 = vp(self.E3.data_ptr())
+        else:
+            self._pE = vp(self.E.data_ptr())
+        self._pE2 = vp(self.E2.data_ptr())
+        self._pY = [vp(t.data_ptr()) for t in self.Ybuf]
+        self._pez = [vp(t.data_ptr()) for t in self.ezbuf]
+        self._pgrads = vp(self.grads.data_ptr())
+        self._pwork = vp(self.work.buf.data_ptr())
+        self._h_rng = vp(self.s_rng.cuda_stream) if overlap else None
+        self._main = torch.cuda.current_stream(dev)  # run() re-reads the current stream
+        self._h_main = vp(self._main.cuda_stream)
 
     # -- stage A: the factors of one group of steps (own stream) ---------------------------------------
     def _issue_factors(self, keys, slot):
@@ -383,52 +405,53 @@ class StepEngine():
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
-    def _normals(self, key, buf):
-        """The step's standard normals (Philox streams keyed by rank, key, purpose): E (as bf16 planes on the
-        bf16 x 3 path), E', eps_z into draw buffer `buf`."""
+    def _normals(self, key, buf, h):
+        """The step's standard normals (Philox streams keyed by rank, key, purpose — parallel.philox_stream_id):
+        E (as bf16 planes on the bf16 x 3 path), E', eps_z into draw buffer `buf`, on the stream with handle h."""
+        lib, n, B, seed = self._lib, self.n, self.B, self.seed
+        sid = ((self.rank & 0xFF) << 56) | ((int(key[0]) & 0xFFFFFF) << 28) | ((int(key[-1]) & 0xFFFFFF) << 4)
         if self.b3:
-            ops.randn_b3(None, out=self.E3, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
+            rc = lib.gpvae_randn_b3(h, B * n, seed, sid | 1, self._pE3, B * n)
         else:
-            ops.randn(None, out=self.E, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 1))
-        ops.randn(None, out=self.E2, seed=self.seed, stream_id=philox_stream_id(self.rank, key, 2))
-        ops.randn(None, out=self.ezbuf[buf], seed=self.seed, stream_id=philox_stream_id(self.rank, key, 3))
+            rc = lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 1, self._pE)
+        rc = rc or lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 2, self._pE2)
+        rc = rc or lib.gpvae_randn(h, self._dtc, B * self.z, seed, sid | 3, self._pez[buf])
+        if rc:
+            check(rc, "gpvae_randn")
 
     def _produce(self, key, slot, i, last_of_group, buf, next_key=None):
         """The B draws of one step into draw buffer `buf` (main stream).  The normals of the NEXT step are
         generated on a side stream as soon as this draw has read E / E' — beside the ELBO chain of this
         step, whose small latency-bound kernels leave most CUs idle (they were 36 us of the main
         stream's critical path)."""
-        main = torch.cuda.current_stream()
+        main, hm = self._main, self._h_main
         if self.overlap and i == 0:
             main.wait_event(self.ev_ready[slot])
         if self._rng_pending:
             main.wait_event(self.ev_rng)      # this step's normals came from the side stream
             self._rng_pending = False
         else:
-            self._normals(key, buf)
-        K = self.Kbuf[slot][i]
-        sig = self.hyper_dev[slot][2, i:i + 1]
-        lib = _lib.load()
+            self._normals(key, buf, hm)
+        lib, n = self._lib, self.n
         if self.draw_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
         if self.b3:
-            L3, n = self.L3buf[slot][i], self.n
-            check(lib.gpvae_draw_b3(_stream(), n, self.B, _p(L3), n, n * n, _p(self.E3), n, self.B * n,
-                                    _p(self.E2), n, _p(sig), None, 0, _p(self.Ybuf[buf]), n), "gpvae_draw_b3")
+            rc = lib.gpvae_draw_b3(hm, n, self.B, self._pL3[slot][i], n, n * n, self._pE3, n, self.B * n,
+                                   self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
         else:
-            check(lib.gpvae_draw(_stream(), _dt(K), self.n, self.B, _p(K), self.ld, _p(self.E), self.n,
-                                 _p(self.E2), self.n, _p(sig), None, 0, _p(self.Ybuf[buf]), self.n),
-                  "gpvae_draw")
+            rc = lib.gpvae_draw(hm, self._dtc, n, self.B, self._pK[slot][i], self.ld, self._pE, n,
+                                self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
+        if rc:
+            check(rc, "gpvae_draw")
         if self.draw_events is not None:
             ev[1].record(main)
             self.draw_events.append(ev)
         if self.overlap and next_key is not None:
             self.ev_drawn.record(main)
             self.s_rng.wait_event(self.ev_drawn)
-            with torch.cuda.stream(self.s_rng):
-                self._normals(next_key, buf ^ 1)
-                self.ev_rng.record(self.s_rng)
+            self._normals(next_key, buf ^ 1, self._h_rng)
+            self.ev_rng.record(self.s_rng)
             self._rng_pending = True
         if self.overlap and last_of_group:
             self.ev_free[slot].record(main)
@@ -436,16 +459,23 @@ class StepEngine():
     def _learn_start(self, buf, state, train, t=0):
         """ELBO (+ gradient) of the step in draw buffer `buf`; starts the one collective of the path
         (flat-gradient SUM, RCCL over xGMI) and returns its handle."""
-        self.loss = self.loss_steps[t:t + 1]  # one slot per step: summed once at the end of run()
-        ops.vae_elbo(state.params, self.Ybuf[buf], self.ezbuf[buf], (self.h0, self.h1, self.z),
-                     self.obs_sigma, grads=self.grads if train else None, loss=self.loss, work=self.work)
-        return allreduce_sum_start(self.grads) if train else None
+        rc = self._lib.gpvae_vae_elbo(self._h_main, self._dtc, self.B, self.n, self.h0, self.h1, self.z, self._pparams,
+                                      self._pY[buf], self.n, self._pez[buf], float(self.obs_sigma),
+                                      C.c_void_p(self._loss_base + t * self._loss_es),
+                                      self._pgrads if train else None, self._pwork)
+        if rc:
+            check(rc, "gpvae_vae_elbo")
+        return allreduce_sum_start(self.grads) if (train and self._collective) else None
 
     def _learn_finish(self, handle, state, train):
         if train:
-            allreduce_wait(handle)
+            if handle is not None:
+                allreduce_wait(handle)
             state.t += 1
-            ops.adam_(state.params, self.grads, state.m, state.v, state.t, self.lr)
+            rc = self._lib.gpvae_adam(self._h_main, self._dtc, self._nparams, self._pparams, self._pgrads, self._pm,
+                                      self._pv, int(state.t), float(self.lr), 0.9, 0.999, 1e-8)
+            if rc:
+                check(rc, "gpvae_adam")
 
     def failed_factors(self):
         """Number of Gram matrices gpvae_potrf reported as not positive definite since the engine was
@@ -463,6 +493,17 @@ class StepEngine():
         if not keys:
             return self.loss_sum
         self.loss_steps = torch.zeros(len(keys), dtype=self.dtype, device=self.x.device)
+        self.loss = self.loss_steps[-1:]  # the last step's loss
+        # per-run raw handles for the step path (the current stream is the main stream of this run)
+        self._main = torch.cuda.current_stream()
+        self._h_main = C.c_void_p(self._main.cuda_stream)
+        self._loss_base, self._loss_es = self.loss_steps.data_ptr(), self.loss_steps.element_size()
+        if state.params.device != self.x.device or state.params.dtype != self.dtype or not state.params.is_contiguous():
+            raise GpvaeError("StepEngine.run: state.params must be a contiguous %s tensor on %s" % (self.dtype, self.x.device))
+        self._pparams, self._pm, self._pv = (C.c_void_p(a.data_ptr()) for a in (state.params, state.m, state.v))
+        self._nparams = state.params.numel()
+        from .parallel import _collective_on
+        self._collective = _collective_on()
         # the first group is exposed (nothing to overlap it with).  Measured on 20-step runs at C3 (ms per
         # step): first group of 2: 1.08, 4: 1.06, 8: 1.05, a full group of 16: 0.98 — small batches factor
         # too slowly (latency-bound launch chain) for a short first group to pay; `first_group` overrides

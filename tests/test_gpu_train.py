@@ -87,6 +87,27 @@ def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
         StepEngine(torch.tensor(np.arange(300) / 300), jit, dims, 100, lr, mfma="bf16x3")
 
 
+def test_training_run_is_bitwise_reproducible():
+    """Two training runs from the same seed end in the same bits (parameters, Adam moments, summed loss): no
+    kernel on the step's path sums with floating-point atomics, and nothing depends on how the factor
+    stream and the draw / ELBO stream interleave.  Both matrix pipes, and the 1-D unfused shapes."""
+    from gp_vae_amd.vae import StepEngine, SVIState
+    g = np.arange(0, 1, 1 / 32)
+    u, v = np.meshgrid(g, g)
+    x2 = np.stack([u.ravel(), v.ravel()], 1)
+    cases = [(x2, 256, (20, 12, 5), "bf16x3"), (x2, 256, (20, 12, 5), "f32"), (np.arange(300) / 300, 100, (35, 30, 10), "auto")]
+    for x, B, dims, mode in cases:
+        outs = []
+        for rep in range(2):
+            eng = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float32, seed=3, group=4, mfma=mode)
+            p0 = orc.flatten({k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), x.shape[0], *dims, np.float64).items()})
+            st = SVIState(torch.tensor(p0, dtype=torch.float32, device=DEV))
+            loss = eng.run([(0, i) for i in range(9)], st, train=True)
+            outs.append((loss.clone(), st.params.clone(), st.m.clone(), st.v.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(*outs)), mode
+        assert torch.isfinite(outs[0][1]).all()
+
+
 def test_vae_fit_reference_surface_trains():
     from gp_vae_amd.gp import GP, Predictive, exp_kernel2
     from gp_vae_amd.vae import VAE
