@@ -38,30 +38,27 @@ static inline MvnWork mvn_layout(int64_t n) {
   return w;
 }
 
-// X_b = [I_n ; f_b^T]; logp_b = -n/2 log 2pi; the two gradient accumulators = 0.  grid (rows, batch)
+// Sums over rows and tiles are kept as parts (one per row / per tile) and added in a fixed order by
+// mvn_reduce_kernel: no floating-point atomics, so a chain's numbers are the same bits on every call and do
+// not depend on which other chains share the batch.
+// X_b = [I_n ; f_b^T].  grid (rows, batch)
 template <typename T>
-__global__ void mvn_fill_kernel(int64_t n, T *X, int64_t ldx, int64_t strideX, const T *f, T *logp,
-                                T *acc2) {
+__global__ void mvn_fill_kernel(int64_t n, T *X, int64_t ldx, int64_t strideX, const T *f) {
   const int64_t b = blockIdx.y;
   const int64_t i = blockIdx.x;  // row 0..n
   T *row = X + b * strideX + i * ldx;
   for (int64_t k = threadIdx.x; k < n; k += blockDim.x)
     row[k] = (i < n) ? (k == i ? T(1) : T(0)) : f[b * n + k];
-  if (i == 0 && threadIdx.x == 0) {
-    logp[b] = T(-0.9189385332046727) * (T)n;
-    acc2[2 * b] = T(0);
-    acc2[2 * b + 1] = T(0);
-  }
 }
 
-// one wave per row i: alpha_i = U[i,:] . w ; logp -= log L_ii + w_i^2 / 2 ; the row's share of the
+// one wave per row i: alpha_i = U[i,:] . w ; the row's part of logp: -(log L_ii + w_i^2 / 2) ; its part of the
 // d/dvar sum: (w_i^2 - 1) - jitter (alpha_i^2 - |U[i,:]|^2).  grid (ceil(n/4), batch)
 template <typename T>
 __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, int64_t lda,
                                                          int64_t strideA, const T *X, int64_t ldx,
                                                          int64_t strideX, const int32_t *info,
-                                                         T *alpha, T *grad_f, T *logp, T jitter,
-                                                         T *acc2) {
+                                                         T *alpha, T *grad_f, T jitter, T *part,
+                                                         int64_t pstride) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t b = blockIdx.y;
@@ -82,8 +79,9 @@ __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, 
     alpha[b * n + i] = a;
     if (grad_f) grad_f[b * n + i] = -a;
     const T lii = A[b * strideA + i * lda + i];
-    atomicAdd(&logp[b], bad ? dnan<T>() : -(dlog<T>(lii) + T(0.5) * w[i] * w[i]));
-    if (acc2 != nullptr) atomicAdd(&acc2[2 * b], (w[i] * w[i] - T(1)) - jitter * (a * a - usq));
+    T *pb = part + b * pstride;
+    pb[i] = bad ? dnan<T>() : -(dlog<T>(lii) + T(0.5) * w[i] * w[i]);
+    pb[n + i] = (w[i] * w[i] - T(1)) - jitter * (a * a - usq);
   }
 }
 
@@ -91,7 +89,7 @@ __global__ __launch_bounds__(256) void mvn_finish_kernel(int64_t n, const T *A, 
 template <typename T, int D, bool VECM>
 __global__ __launch_bounds__(NTHREADS, 2) void mvn_grad_kernel(
     int64_t n, const T *X, int64_t ldx, int64_t strideX, const T *x, const T *var_p, const T *ls_p,
-    const T *alpha, T *acc2) {
+    const T *alpha, T *part, int64_t pstride) {
   using M = Mfma<T>;
   constexpr int BM = 128, BK = TileK<T>::BK, F = 64 / M::TM;
   using LA = LoaderKC<T, BM, BK, VECM>;
@@ -144,18 +142,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void mvn_grad_kernel(
   s2 = wave_sum<T>(s2);
   if (lane == 0) red[wave] = s2;
   __syncthreads();
-  if (tid == 0) atomicAdd(&acc2[2 * b + 1], red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0)
+    part[b * pstride + 2 * n + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// grad_var = s1 / (2 var), grad_ls = s2 / (2 ls^3); NaN when the factorisation failed
+// one workgroup per chain: logp = -n/2 log 2pi + sum of the row parts; grad_var = s1 / (2 var),
+// grad_ls = s2 / (2 ls^3) from the row / tile parts (NaN when the factorisation failed).  Thread t adds parts
+// t, t + 256, ... in order, then a fixed tree over the 256 threads.
 template <typename T>
-__global__ void mvn_scale_kernel(int batch, const T *var, const T *ls, const int32_t *info,
-                                 const T *acc2, T *grad_var, T *grad_ls) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
+__device__ __forceinline__ T block_sum_ordered(const T *p, int64_t cnt, T *red, int tid) {
+  T a = T(0);
+  for (int64_t i = tid; i < cnt; i += 256) a += p[i];
+  __syncthreads();  // red may still be read by the previous call
+  red[tid] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  return red[0];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mvn_reduce_kernel(int64_t n, int64_t ntile2, const T *var, const T *ls,
+                                                         const int32_t *info, const T *part, int64_t pstride,
+                                                         T *logp, T *grad_var, T *grad_ls) {
+  __shared__ T red[256];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const T *pb = part + b * pstride;
   const bool bad = info[b] != 0;
-  if (grad_var) grad_var[b] = bad ? dnan<T>() : acc2[2 * b] / (T(2) * var[b]);
-  if (grad_ls) grad_ls[b] = bad ? dnan<T>() : acc2[2 * b + 1] / (T(2) * ls[b] * ls[b] * ls[b]);
+  const T lp = block_sum_ordered<T>(pb, n, red, tid);
+  if (tid == 0) logp[b] = T(-0.9189385332046727) * (T)n + lp;
+  if (grad_var != nullptr) {
+    const T s1 = block_sum_ordered<T>(pb + n, n, red, tid);
+    if (tid == 0) grad_var[b] = bad ? dnan<T>() : s1 / (T(2) * var[b]);
+  }
+  if (grad_ls != nullptr) {
+    const T s2 = block_sum_ordered<T>(pb + 2 * n, ntile2, red, tid);
+    if (tid == 0) grad_ls[b] = bad ? dnan<T>() : s2 / (T(2) * ls[b] * ls[b] * ls[b]);
+  }
 }
 
 
@@ -223,26 +248,27 @@ static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const
   T *A = (T *)work;                         // [batch][n][lda]
   T *X = A + (int64_t)batch * w.a_elems;    // [batch][n + 1][lda]
   T *alpha = X + (int64_t)batch * w.x_elems;  // [batch][n]
-  T *acc2 = alpha + (int64_t)batch * n;       // [batch][2]
-  char *pw = (char *)(acc2 + 2 * (int64_t)batch);
+  const int64_t nt = cdiv(n, 128), pstride = 2 * n + nt * nt;
+  T *part = alpha + (int64_t)batch * n;       // [batch][n row parts of logp | n of d/dvar | nt^2 tile parts of d/dls]
+  char *pw = (char *)(part + pstride * (int64_t)batch);
   pw = (char *)(((uintptr_t)pw + 15) & ~(uintptr_t)15);
   int rc = gpvae_gram_se((void *)st, dtype, d, n, n, x, x, batch, var, ls, jitter, A, w.lda, w.a_elems);
   if (rc) return rc;
   hipLaunchKernelGGL((mvn_fill_kernel<T>), dim3((unsigned)(n + 1), (unsigned)batch), dim3(256), 0, st,
-                     n, X, w.lda, w.x_elems, (const T *)f, (T *)logp, acc2);
+                     n, X, w.lda, w.x_elems, (const T *)f);
   rc = gpvae_potrf((void *)st, dtype, n, batch, A, w.lda, w.a_elems, n + 1, X, w.lda, w.x_elems, info,
                    0, pw);
   if (rc) return rc;
   hipLaunchKernelGGL((mvn_finish_kernel<T>), dim3((unsigned)cdiv(n, 4), (unsigned)batch), dim3(256),
                      0, st, n, A, w.lda, w.a_elems, X, w.lda, w.x_elems, info, alpha, (T *)grad_f,
-                     (T *)logp, (T)jitter, grad_var ? acc2 : (T *)nullptr);
+                     (T)jitter, part, pstride);
   if (grad_ls) {
     const dim3 grid((unsigned)cdiv(n, 128), (unsigned)cdiv(n, 128), (unsigned)batch);
     const bool vec = kc_vec_ok<T>(X, w.lda) && (w.x_elems % VecT<T>::N) == 0;
     auto launch = [&](auto dd, auto vv) {
       hipLaunchKernelGGL((mvn_grad_kernel<T, decltype(dd)::value, decltype(vv)::value>), grid,
                          dim3(NTHREADS), 0, st, n, X, w.lda, w.x_elems, (const T *)x, (const T *)var,
-                         (const T *)ls, alpha, acc2);
+                         (const T *)ls, alpha, part, pstride);
     };
     if (d == 1) {
       if (vec) launch(std::integral_constant<int, 1>{}, std::true_type{});
@@ -252,9 +278,8 @@ static int run_mvn(hipStream_t st, int dtype, int d, int64_t n, int batch, const
       else launch(std::integral_constant<int, 2>{}, std::false_type{});
     }
   }
-  if (grad_var || grad_ls)
-    hipLaunchKernelGGL((mvn_scale_kernel<T>), dim3((unsigned)cdiv(batch, 256)), dim3(256), 0, st, batch,
-                       (const T *)var, (const T *)ls, info, acc2, (T *)grad_var, (T *)grad_ls);
+  hipLaunchKernelGGL((mvn_reduce_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, n, nt * nt, (const T *)var,
+                     (const T *)ls, info, (const T *)part, pstride, (T *)logp, (T *)grad_var, (T *)grad_ls);
   GPVAE_CHECK_LAUNCH("gpvae_mvn_logp");
   return 0;
 }
@@ -267,7 +292,8 @@ extern "C" int64_t gpvae_mvn_workspace_bytes(int dtype, int64_t n, int batch) {
   if (n <= 0 || batch <= 0) return 0;
   const MvnWork w = mvn_layout(n);
   const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
-  return (int64_t)batch * (w.a_elems + w.x_elems + n + 2) * es + 256 +
+  const int64_t nt = cdiv(n, 128);
+  return (int64_t)batch * (w.a_elems + w.x_elems + 3 * n + nt * nt) * es + 256 +
          gpvae_potrf_workspace_bytes(dtype, n, n + 1, batch);
 }
 

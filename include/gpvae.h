@@ -208,7 +208,9 @@ int gpvae_krig_predict_batched(void *stream, int dtype, int d, int64_t n_obs, in
  *   grad_var[b], grad_ls[b] = d logp / d var, d logp / d ls   (closed form; may be NULL)
  * info: int32[batch] potrf status; a chain whose K is not positive definite gets NaN outputs.
  * work: gpvae_mvn_workspace_bytes() bytes (about batch*(2n+1)*n*s).  The reference obtains the
- * gradient by reverse-mode through jnp.linalg.cholesky; values agree, the arithmetic differs.     */
+ * gradient by reverse-mode through jnp.linalg.cholesky; values agree, the arithmetic differs.
+ * Reproducible: row and tile sums are added in a fixed order (no floating-point atomics), and a chain's
+ * results do not depend on which other chains share the batch.                                    */
 int64_t gpvae_mvn_workspace_bytes(int dtype, int64_t n, int batch);
 int gpvae_mvn_logp(void *stream, int dtype, int d, int64_t n, int batch, const void *x,
                    const void *f, const void *var, const void *ls, double jitter, void *logp,
