@@ -79,6 +79,36 @@ def test_argument_validation_without_a_gpu():
     assert lib.gpvae_decoder_vjp_static(null, 0, 0, 300, 35, 30, 10, null, null, null, null) == 0
 
 
+def test_argument_validation_of_the_round_2_entry_points():
+    """Bad arguments come back as negative codes with a reason, before any launch; empty problems are no-ops."""
+    lib = _lib.load()
+    null, one = C.c_void_p(0), C.c_void_p(16)
+    assert lib.gpvae_gp_potential(null, 5, 1, 10, 4, one, one, 13, one, None, 10, 1e-5, one, one, 13, None, one) == -2
+    assert lib.gpvae_gp_potential(null, 0, 3, 10, 4, one, one, 13, one, None, 10, 1e-5, one, one, 13, None, one) == -3
+    assert lib.gpvae_gp_potential(null, 0, 1, 10, 4, one, one, 12, one, None, 10, 1e-5, one, one, 13, None, one) == -8
+    assert b"ldq" in lib.gpvae_last_error()
+    assert lib.gpvae_gp_potential(null, 0, 1, 10, 4, one, one, 13, one, None, 5, 1e-5, one, one, 13, None, one) == -11  # n_lik != n without lik_idx
+    assert lib.gpvae_gp_potential(null, 0, 1, 10, 0, null, null, 13, null, None, 10, 1e-5, null, null, 13, None, null) == 0
+    assert lib.gpvae_mvn_logp(null, 9, 1, 10, 4, one, one, one, one, 1e-5, one, null, null, null, None, one) == -2
+    assert lib.gpvae_mvn_logp(null, 0, 1, 10, 70000, one, one, one, one, 1e-5, one, null, null, null, None, one) == -5
+    assert lib.gpvae_mvn_logp(null, 0, 1, 10, 0, null, null, null, null, 1e-5, null, null, null, null, None, null) == 0
+    # bf16 x 3 entry points: shapes the tiling does not take are refused, not mis-computed
+    assert lib.gpvae_draw_b3_supported(4096, 4096) == 1 and lib.gpvae_draw_b3_supported(300, 100) == 0
+    assert lib.gpvae_draw_b3_supported(4096, 100) == 0 and lib.gpvae_potrf_b3_supported(300) == 0
+    assert lib.gpvae_potrf_b3_supported(4096) == 1 and lib.gpvae_potrf_b3_supported(256) == 0
+    assert lib.gpvae_draw_b3(null, 300, 256, one, 304, 304 * 300, one, 304, 256 * 304, null, 0, null, null, 0, one, 304) < 0
+    assert b"gpvae_draw_b3" in lib.gpvae_last_error()
+    assert lib.gpvae_potrf_b3(null, 300, 1, one, 300, 90000, None, 0, one, one, 304, 304 * 300, 3 * 304 * 300) < 0
+    assert lib.gpvae_randn_b3(null, 6, 1, 2, one, 8) < 0          # count % 4 != 0
+    assert lib.gpvae_randn_b3(null, 0, 1, 2, null, 0) == 0
+    assert lib.gpvae_split_b3(null, 8, 8, 1, null, 8, 64, 0, one, 8, 64, 192) < 0  # X NULL
+    assert lib.gpvae_hyper_sample(null, 3, 4, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # dtype
+    assert lib.gpvae_hyper_sample(null, 0, 4, 1, 2, 0, 7, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # prior id
+    assert lib.gpvae_hyper_sample(null, 0, 0, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, null, null, null) == 0
+    assert lib.gpvae_vae_potential_supported(0, 35, 30, 10, 10) == 1 and lib.gpvae_vae_potential_supported(0, 1024, 1024, 64, 4096) == 0
+    assert lib.gpvae_vae_potential(null, 0, 4, 300, 1024, 1024, 64, one, one, 65, one, None, 4096, 0.1, one, one, 65) < 0
+
+
 def test_size_queries():
     lib = _lib.load()
     n, h0, h1, z = 300, 35, 30, 10
