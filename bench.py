@@ -360,6 +360,7 @@ def main():
     draw_ms = float(np.mean([a.elapsed_time(b) for a, b in eng.draw_events])) if eng.draw_events else None
     eng.draw_events = None
     loss_last = float(eng.loss.item())
+    draw_alone_ms = eng.time_draw_alone() if rank == 0 else None
 
     # batched Cholesky microbenchmark: every rank factors its own batch (weak), TFLOP/s summed
     chol = [potrf_microbench(ops, x, batch=32), potrf_microbench(ops, x, batch=args.group),
@@ -394,6 +395,9 @@ def main():
                     "avg_launch_ms": draw_ms, "flop_per_launch": 6 * flop, "algorithmic_flop_per_launch": flop,
                     "f32_equivalent_tflops": f32_equiv,
                     "f32_equivalent_frac_of_f32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS if f32_equiv else None}
+            if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
+                roof["avg_launch_ms_alone"] = draw_alone_ms
+                roof["frac_alone"] = 6 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
         else:
             roof = {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "mfma": "f32", "bound": "mfma",
                     "achieved": f32_equiv, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -477,6 +477,25 @@ class StepEngine():
             if rc:
                 check(rc, "gpvae_adam")
 
+    def time_draw_alone(self, reps=16):
+        """Average duration (ms, HIP events) of the step's draw launched back to back with nothing beside it on
+        the chip — the kernel's own time, as a kernel trace reports it; bench.py quotes it next to the in-loop
+        figure, whose events also see the wait for CUs the factor stream holds."""
+        torch.cuda.synchronize()
+        main = torch.cuda.current_stream()
+        self._main, self._h_main = main, C.c_void_p(main.cuda_stream)
+        keep, self.draw_events = self.draw_events, []
+        was, self.overlap = self.overlap, False
+        try:
+            for r in range(reps + 2):
+                self._rng_pending = True  # keep the normals already in the buffers: time the draw only
+                self._produce((0, 0), 0, 0, False, 0)
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self.draw_events[2:]]
+        finally:
+            self.overlap, self.draw_events, self._rng_pending = was, keep, False
+        return sum(ms) / len(ms)
+
     def failed_factors(self):
         """Number of Gram matrices gpvae_potrf reported as not positive definite since the engine was
         built (synchronises).  Such a step trains on a NaN batch, as the reference's does (SURVEY.md
