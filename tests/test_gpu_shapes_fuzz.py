@@ -222,3 +222,39 @@ def test_kriging_batched_random_shapes_f64(ops):
             tag = (case, n_obs, n_test, d, S, s)
             assert rel(m[s], mo) < 1e-7 and rel(p[s], po) < 1e-6, tag
             assert np.abs(v[s].cpu().numpy() - vo).max() < 1e-8, tag
+
+
+def test_gp_potential_random_shapes_f64(ops):
+    """gpvae_gp_potential over ragged sizes, both point dimensions, padded q / dU rows and ragged chain
+    counts: the potential against the oracle's gp_regression potential, its gradient against central
+    differences of the same oracle (a few coordinates per case), and chain c of a batch against the same chain
+    evaluated alone (fixed-order sums: bit for bit)."""
+    rng = np.random.default_rng(23)
+    for case in range(8):
+        n = int(rng.choice([1, 3, 31, 64, 65, 129, 200]))
+        d = int(rng.choice([1, 2]))
+        C = int(rng.choice([1, 2, 5, 9]))
+        x = rng.random((n, d))
+        y = np.sin(5 * x[:, 0]) + 0.1 * rng.standard_normal(n)
+        uv, ul, us = 0.1 * rng.standard_normal(C), np.log(rng.uniform(0.15, 0.4, C)), np.log(rng.uniform(0.05, 0.2, C))
+        F = np.stack([np.linalg.cholesky(orc.exp_kernel2(x, x, np.exp(uv[c]), np.exp(ul[c]), 1e-5)) @ rng.standard_normal(n) for c in range(C)])
+        q = np.concatenate([F, uv[:, None], ul[:, None], us[:, None]], 1)
+        xs = x if d == 2 else x[:, 0]
+        xd = torch.tensor(xs, dtype=torch.float64, device=DEV)
+        qd = padded(q, torch.float64, 5)
+        U, dU, info = ops.gp_potential(xd, qd, torch.tensor(y, dtype=torch.float64, device=DEV))
+        tag = (case, n, d, C)
+        assert (info == 0).all(), tag
+        for c in range(C):
+            want = orc.gp_regression_potential(xs, y, q[c, :n], uv[c], ul[c], us[c])
+            assert abs(U[c].item() - want) < 1e-8 * max(1.0, abs(want)), tag + (c,)
+        c = int(rng.integers(C))
+        for j in {0, n // 2, n - 1, n, n + 1, n + 2}:
+            h = 1e-6
+            qp, qm = q[c].copy(), q[c].copy()
+            qp[j] += h; qm[j] -= h
+            fd = (orc.gp_regression_potential(xs, y, qp[:n], qp[n], qp[n + 1], qp[n + 2])
+                  - orc.gp_regression_potential(xs, y, qm[:n], qm[n], qm[n + 1], qm[n + 2])) / (2 * h)
+            assert abs(dU[c, j].item() - fd) < 2e-4 * max(1.0, abs(fd)), tag + (c, j, dU[c, j].item(), fd)
+        U1, dU1, _ = ops.gp_potential(xd, qd[c:c + 1], torch.tensor(y, dtype=torch.float64, device=DEV))
+        assert torch.equal(U1[0], U[c]) and torch.equal(dU1[0], dU[c]), tag
