@@ -223,6 +223,21 @@ def extras(ops, x, dev):
     t = _event_time(lambda: inf.potential_and_grad(z, lsig), 200)
     out["c5"] = {"workload": "C5: VAEInference.regression potential + gradient, 1024 chains, decoder 10-30-35-300, f32",
                  "grad_evals_per_s": 1024 / t, "ms_per_batched_eval": t * 1e3}
+    # the same model under the batched NUTS (gpvae_nuts_op transition + gpvae_vae_potential), end to end
+    y5 = np.full(n5, np.nan)
+    y5[[20, 23, 100, 110, 117, 130, 133, 140, 170, 190]] = np.sin(6 * x5[[20, 23, 100, 110, 117, 130, 133, 140, 170, 190]])
+    inf = VAEInference(None, dec, dims5[2], 1, x5, y5, [20, 23, 100, 110, 117, 130, 133, 140, 170, 190],
+                       {"num_warmup": 100, "num_samples": 100, "num_chains": 1024, "thinning": 1}, seed=1, dtype=torch.float32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inf.run_mcmc(3)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    lf = float(inf.mcmc_info["leapfrogs_per_iteration"].mean().item())
+    out["c5_nuts"] = {"workload": "C5 end to end: run_mcmc, batched NUTS, 1024 chains, 100 warm-up + 100 sampling iterations",
+                      "wall_s": t, "chain_iterations_per_s": 1024 * 200 / t, "leapfrogs_per_iteration": lf,
+                      "accept_prob": float(inf.mcmc_info["accept_prob"].mean().item()),
+                      "divergent": int(inf.mcmc_info["divergent"])}
     return out
 
 

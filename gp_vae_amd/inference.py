@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from . import ops
 from .hmc import hmc
-from .nuts import nuts, uniforms_per_iteration
+from .nuts import nuts, nuts_device, uniforms_per_iteration
 from ._lib import GpvaeError
 from .gp import _as_device, _key_parts, _seed_of, exp_kernel2
 from .parallel import dist_info, shard
@@ -107,7 +107,9 @@ class Inference():
             return g[:, :D], (unif if kernel == "nuts" else unif[:, 0])
 
         if kernel == "nuts":
-            smp, info = nuts(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
+            # the transition runs in libgpvae_hip (gpvae_nuts_op); "nuts_driver": "torch" keeps the torch restatement
+            run = nuts if a.get("nuts_driver", "device") == "torch" else nuts_device
+            smp, info = run(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
                              thinning=int(a.get("thinning", 1)), max_tree_depth=depth, seed=seed + 1,
                              noise_fn=noise_fn)
         else:

@@ -14,6 +14,7 @@ batch (that is how the HIP kernels behind it — gpvae_vae_potential, gpvae_gp_p
 called); chains whose tree has stopped ride along masked, so a chain's trajectory depends only on its
 own numbers.  The tree depth of an iteration is the deepest tree of the batch.
 """
+import ctypes as C
 import math
 
 import torch
@@ -68,6 +69,51 @@ class _Windows():
             lo, size = hi, 2 * size
 
 
+class _Adapter():
+    """Warm-up adaptation per chain: dual-averaging step size (Hoffman & Gelman 2014, alg. 5) and a diagonal
+    mass matrix estimated over Stan's windows (Welford), with the step-size search restarted at each window's
+    end.  Shared by the torch and the device drivers."""
+
+    def __init__(self, C, D, dt, dev, step_size, target_accept, num_warmup, adapt_mass_matrix):
+        self.minv = torch.ones((C, D), dtype=dt, device=dev)  # inverse mass diagonal, per chain
+        self.log_eps = torch.full((C,), math.log(step_size), dtype=dt, device=dev)
+        self.log_eps_bar = self.log_eps.clone()
+        self.h_bar = torch.zeros(C, dtype=dt, device=dev)
+        self.mu = self.log_eps + math.log(10.0)
+        self.target = target_accept
+        self.m = 0
+        self.win = _Windows(num_warmup if adapt_mass_matrix else 0)
+        self.w_n, self.w_mean, self.w_m2 = 0, torch.zeros((C, D), dtype=dt, device=dev), torch.zeros((C, D), dtype=dt, device=dev)
+
+    def step_size(self, warm):
+        return torch.exp(self.log_eps if warm else self.log_eps_bar)
+
+    def update(self, it, a, q):
+        gamma, t0, kappa = 0.05, 10.0, 0.75
+        self.m += 1
+        m = self.m
+        self.h_bar = (1 - 1 / (m + t0)) * self.h_bar + (self.target - a) / (m + t0)
+        self.log_eps = self.mu - math.sqrt(m) / gamma * self.h_bar
+        w = m ** (-kappa)
+        self.log_eps_bar = w * self.log_eps + (1 - w) * self.log_eps_bar
+        win = self.win
+        if win.ends and it >= win.start:
+            self.w_n += 1
+            d1 = q - self.w_mean
+            self.w_mean = self.w_mean + d1 / self.w_n
+            self.w_m2 = self.w_m2 + d1 * (q - self.w_mean)
+            if it in win.ends and self.w_n > 1:
+                n = self.w_n
+                var = self.w_m2 / (n - 1)
+                self.minv = (n / (n + 5.0)) * var + 1.0e-3 * (5.0 / (n + 5.0))
+                self.w_n, self.w_mean, self.w_m2 = 0, torch.zeros_like(q), torch.zeros_like(q)
+                # restart the step-size search around the last averaged value
+                self.log_eps = self.log_eps_bar.clone()
+                self.mu = self.log_eps + math.log(10.0)
+                self.h_bar = torch.zeros_like(self.h_bar)
+                self.m = 0
+
+
 def nuts(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_depth=10, step_size=0.1,
          target_accept=0.8, seed=0, noise_fn=None, adapt_mass_matrix=True):
     """potential_and_grad(q [C, D]) -> (U [C], dU/dq [C, D]).  q0: [C, D] initial positions.
@@ -88,15 +134,8 @@ def nuts(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_d
     U, g = potential_and_grad(q)
     if not torch.isfinite(U).all():
         raise ValueError("nuts: the potential is not finite at the initial positions")
-    minv = torch.ones((C, D), dtype=dt, device=dev)  # inverse mass diagonal, per chain
-    log_eps = torch.full((C,), math.log(step_size), dtype=dt, device=dev)
-    log_eps_bar = log_eps.clone()
-    h_bar = torch.zeros(C, dtype=dt, device=dev)
-    mu = log_eps + math.log(10.0)
-    gamma, t0, kappa = 0.05, 10.0, 0.75
-    m_da = 0
-    win = _Windows(num_warmup if adapt_mass_matrix else 0)
-    w_n, w_mean, w_m2 = 0, torch.zeros_like(q), torch.zeros_like(q)
+    ad = _Adapter(C, D, dt, dev, step_size, target_accept, num_warmup, adapt_mass_matrix)
+    minv = ad.minv
     keep = []
     acc_stat = torch.zeros(C, dtype=dt, device=dev)
     n_div = torch.zeros((), dtype=torch.long, device=dev)
@@ -105,7 +144,8 @@ def nuts(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_d
 
     for it in range(num_warmup + num_samples):
         warm = it < num_warmup
-        eps = torch.exp(log_eps if warm else log_eps_bar)
+        eps = ad.step_size(warm)
+        minv = ad.minv
         if noise_fn is None:
             z = torch.randn((C, D), dtype=dt, device=dev, generator=gen)
             unif = torch.rand((C, K), dtype=dt, device=dev, generator=gen)
@@ -179,25 +219,7 @@ def nuts(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_d
         q, U, g = q_prop, U_prop, g_prop
         a = sum_acc / torch.clamp(n_prop, min=1.0)
         if warm:
-            m_da += 1
-            h_bar = (1 - 1 / (m_da + t0)) * h_bar + (target_accept - a) / (m_da + t0)
-            log_eps = mu - math.sqrt(m_da) / gamma * h_bar
-            w = m_da ** (-kappa)
-            log_eps_bar = w * log_eps + (1 - w) * log_eps_bar
-            if win.ends and it >= win.start:
-                w_n += 1
-                d1 = q - w_mean
-                w_mean = w_mean + d1 / w_n
-                w_m2 = w_m2 + d1 * (q - w_mean)
-                if it in win.ends and w_n > 1:
-                    var = w_m2 / (w_n - 1)
-                    minv = (w_n / (w_n + 5.0)) * var + 1.0e-3 * (5.0 / (w_n + 5.0))
-                    w_n, w_mean, w_m2 = 0, torch.zeros_like(q), torch.zeros_like(q)
-                    # restart the step-size search around the last averaged value
-                    log_eps = log_eps_bar.clone()
-                    mu = log_eps + math.log(10.0)
-                    h_bar = torch.zeros_like(h_bar)
-                    m_da = 0
+            ad.update(it, a, q)
         else:
             acc_stat += a
             n_div += diverged.sum()
@@ -205,7 +227,115 @@ def nuts(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_d
             if (it - num_warmup) % thinning == 0:
                 keep.append(q.clone())
     samples = torch.stack(keep) if keep else q.new_empty((0, C, D))
-    info = {"accept_prob": acc_stat / max(num_samples, 1), "step_size": torch.exp(log_eps_bar),
-            "inverse_mass": minv, "divergent": int(n_div.item()),
+    info = {"accept_prob": acc_stat / max(num_samples, 1), "step_size": ad.step_size(False),
+            "inverse_mass": ad.minv, "divergent": int(n_div.item()),
+            "leapfrogs_per_iteration": n_leap / max(num_samples, 1)}
+    return samples, info
+
+
+class _Buffers(C.Structure):
+    """gpvae_nuts_buffers of include/gpvae.h."""
+    _vp, _ip = C.c_void_p, C.POINTER(C.c_int32)
+    _fields_ = ([(n, C.c_void_p) for n in ("q", "U", "g", "minv", "eps", "z", "unif")] + [("ldu", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("ql", "pl", "gl", "qr", "pr", "gr", "q_prop", "U_prop", "g_prop", "logW",
+                                             "p_sum", "H0", "sum_acc", "n_prop", "accept", "active", "diverged",
+                                             "qe", "pe", "ge", "es", "sub_logW", "sub_psum", "sq", "sU", "sg",
+                                             "sub_stop", "building", "right", "ck_p", "ck_s", "ph", "qn", "Un", "gn")]
+                + [("ldg", C.c_int64), ("flags", C.c_void_p)])
+
+
+def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_depth=10, step_size=0.1,
+                target_accept=0.8, seed=0, noise_fn=None, adapt_mass_matrix=True):
+    """The same sampler with the transition in libgpvae_hip (gpvae_nuts_op: one wave per chain, two launches
+    per leapfrog step around the caller's potential instead of ~40 elementwise torch kernels).  Same
+    arguments, results and random-number consumption as :func:`nuts`; q0 must be a device tensor."""
+    from . import _lib
+    from ._lib import check
+    from .ops import _dt
+    if not q0.is_cuda:
+        raise _lib.GpvaeError("nuts_device needs device (HIP) tensors; use nuts() on the CPU")
+    lib = _lib.load()
+    q = q0.clone().contiguous()
+    Cn, D = q.shape
+    dev, dt = q.device, q.dtype
+    K = uniforms_per_iteration(max_tree_depth)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    U, g = potential_and_grad(q)
+    if not torch.isfinite(U).all():
+        raise ValueError("nuts: the potential is not finite at the initial positions")
+    U, g = U.clone().contiguous(), g.clone().contiguous()
+    ad = _Adapter(Cn, D, dt, dev, step_size, target_accept, num_warmup, adapt_mass_matrix)
+    vec = lambda: torch.empty((Cn, D), dtype=dt, device=dev)
+    sca = lambda: torch.empty(Cn, dtype=dt, device=dev)
+    flg = lambda: torch.zeros(Cn, dtype=torch.int32, device=dev)
+    t = {n: vec() for n in ("ql", "pl", "gl", "qr", "pr", "gr", "q_prop", "g_prop", "p_sum", "qe", "pe", "ge",
+                            "sub_psum", "sq", "sg", "ph", "qn")}
+    t.update({n: sca() for n in ("U_prop", "logW", "H0", "sum_acc", "n_prop", "accept", "es", "sub_logW", "sU")})
+    t.update({n: flg() for n in ("active", "diverged", "sub_stop", "building", "right")})
+    t["ck_p"] = torch.empty((max_tree_depth + 1, Cn, D), dtype=dt, device=dev)
+    t["ck_s"] = torch.empty((max_tree_depth + 1, Cn, D), dtype=dt, device=dev)
+    t["flags"] = torch.zeros(2, dtype=torch.int32, device=dev)
+    t["z"], t["unif"], t["eps"] = vec(), torch.empty((Cn, K), dtype=dt, device=dev), sca()
+    b = _Buffers()
+    for n, ten in t.items():
+        setattr(b, n, ten.data_ptr())
+    b.q, b.U, b.g = q.data_ptr(), U.data_ptr(), g.data_ptr()
+    b.ldu = K
+    dtc = _dt(q)
+    bp = C.byref(b)
+
+    def op(code, depth=0, leaf=0, lo=0, hi=0):
+        check(lib.gpvae_nuts_op(C.c_void_p(torch.cuda.current_stream().cuda_stream), dtc, code, Cn, D,
+                                max_tree_depth, depth, leaf, lo, hi, bp), "gpvae_nuts_op")
+
+    keep = []
+    acc_stat = torch.zeros(Cn, dtype=dt, device=dev)
+    n_div = torch.zeros((), dtype=torch.long, device=dev)
+    n_leap = torch.zeros(Cn, dtype=dt, device=dev)
+    for it in range(num_warmup + num_samples):
+        warm = it < num_warmup
+        t["eps"].copy_(ad.step_size(warm))
+        minv = ad.minv.contiguous()
+        b.minv = minv.data_ptr()
+        if noise_fn is None:
+            t["z"].copy_(torch.randn((Cn, D), dtype=dt, device=dev, generator=gen))
+            t["unif"].copy_(torch.rand((Cn, K), dtype=dt, device=dev, generator=gen))
+        else:
+            z, unif = noise_fn(it)
+            t["z"].copy_(z)
+            t["unif"].copy_(unif)
+        op(0)
+        for depth in range(max_tree_depth):
+            op(1, depth)
+            leaves = 1 << depth
+            for leaf in range(leaves):
+                op(2, depth)
+                Un, gn = potential_and_grad(t["qn"])
+                if gn.stride(1) != 1 or not Un.is_contiguous():
+                    Un, gn = Un.contiguous(), gn.contiguous()
+                b.Un, b.gn, b.ldg = Un.data_ptr(), gn.data_ptr(), gn.stride(0)
+                lo, hi = _ckpt_range(leaf)
+                op(3, depth, leaf, lo, hi)
+                if leaves >= 8 and (leaf & 3) == 3 and leaf + 1 < leaves and int(t["flags"][0].item()) == 0:
+                    break
+                if leaves >= 8 and (leaf & 3) == 3:
+                    t["flags"][:1].zero_()  # only chains that still build after the next leaves set it again
+            op(4, depth)
+            if int(t["flags"][1].item()) == 0:
+                break
+        op(5)
+        a = t["accept"]
+        if warm:
+            ad.update(it, a.clone(), q.clone())
+        else:
+            acc_stat += a
+            n_div += t["diverged"].sum()
+            n_leap += t["n_prop"]
+            if (it - num_warmup) % thinning == 0:
+                keep.append(q.clone())
+    samples = torch.stack(keep) if keep else q.new_empty((0, Cn, D))
+    info = {"accept_prob": acc_stat / max(num_samples, 1), "step_size": ad.step_size(False),
+            "inverse_mass": ad.minv, "divergent": int(n_div.item()),
             "leapfrogs_per_iteration": n_leap / max(num_samples, 1)}
     return samples, info

@@ -292,6 +292,49 @@ int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int64_t n, int 
                         const int64_t *obs_idx, int64_t n_obs, double noise_scale, void *U, void *dU,
                         int64_t lddu);
 
+/* ---- f4: the batched NUTS transition around a potential ---------------------------------------------
+ * Replaces the per-leapfrog arithmetic of numpyro.infer.NUTS as the reference drives it
+ * (src/model/inference.py:84-95, 477-487; NumPyro itself is third party): multinomial NUTS with the
+ * iterative tree builder, all chains in lock step, one wave per chain.  The potential-and-gradient
+ * evaluation stays the caller's (gpvae_vae_potential / gpvae_gp_potential or any other); this entry point
+ * is everything between two such evaluations, so that a leapfrog step costs two small launches instead
+ * of some forty elementwise ones.  All arrays are device memory of `dtype`, [C, D] row-major or [C]
+ * unless noted; `op` selects the phase (gp_vae_amd/nuts.py `nuts_device` is the driver):
+ *   GPVAE_NUTS_INIT    momentum p0 = z / sqrt(minv), H0, one-node tree at (q, p0, g)
+ *   GPVAE_NUTS_BEGIN   doubling `depth`: direction from unif[:, depth], empty sub-tree at that edge
+ *   GPVAE_NUTS_PRE     half kick and drift from the edge: ph, qn   (then the caller evaluates Un, gn at qn)
+ *   GPVAE_NUTS_POST    second half kick, energy error, divergence (> 1000), multinomial choice inside the
+ *                      sub-tree (unif[:, 2 max_depth + 2^depth - 1 + leaf]), momentum sum, U-turn checks
+ *                      against the checkpoints [ck_lo, ck_hi] of leaf `leaf`; flags[0] |= a chain still builds
+ *   GPVAE_NUTS_MERGE   biased progressive choice between the tree and the new sub-tree
+ *                      (unif[:, max_depth + depth]), edges, weights, U-turn of the whole tree;
+ *                      flags[1] |= a chain is still active
+ *   GPVAE_NUTS_ACCEPT  q, U, g = the proposal; accept[c] = mean acceptance statistic of the tree
+ * BEGIN clears flags.  A chain whose tree has stopped rides along untouched, so its numbers do not depend
+ * on the other chains of the batch.                                                                   */
+enum { GPVAE_NUTS_INIT = 0, GPVAE_NUTS_BEGIN = 1, GPVAE_NUTS_PRE = 2, GPVAE_NUTS_POST = 3, GPVAE_NUTS_MERGE = 4,
+       GPVAE_NUTS_ACCEPT = 5 };
+typedef struct gpvae_nuts_buffers {
+  void *q, *U, *g;                /* chain state: position, potential, gradient */
+  const void *minv, *eps;         /* inverse mass diagonal [C, D], step size [C] */
+  const void *z, *unif;           /* the iteration's normals [C, D] and uniforms [C, ldu] */
+  int64_t ldu;
+  void *ql, *pl, *gl, *qr, *pr, *gr;              /* tree edges */
+  void *q_prop, *U_prop, *g_prop, *logW, *p_sum;  /* proposal, log weight, momentum sum of the tree */
+  void *H0, *sum_acc, *n_prop, *accept;           /* [C] */
+  int32_t *active, *diverged;                     /* [C] */
+  void *qe, *pe, *ge, *es;                        /* moving edge of the sub-tree; signed step [C] */
+  void *sub_logW, *sub_psum, *sq, *sU, *sg;       /* sub-tree weight, momentum sum, proposal */
+  int32_t *sub_stop, *building, *right;           /* [C] */
+  void *ck_p, *ck_s;                              /* checkpoints [max_depth + 1][C][D] */
+  void *ph, *qn;                                  /* PRE's outputs */
+  const void *Un, *gn;                            /* the caller's potential [C] and gradient [C, ldg] at qn */
+  int64_t ldg;
+  int32_t *flags;                                 /* [2] */
+} gpvae_nuts_buffers;
+int gpvae_nuts_op(void *stream, int dtype, int op, int64_t C, int64_t D, int max_depth, int depth, int leaf,
+                  int ck_lo, int ck_hi, const gpvae_nuts_buffers *b);
+
 /* ---- the same VJP with no workspace argument and no allocation ------------------------------------
  * No counterpart in the reference.  For callers that cannot allocate or carry a workspace: code
  * under HIP graph capture, tight MCMC / serving loops, harnesses that forbid hipMalloc.  Same kernels

@@ -471,3 +471,48 @@ def test_vae_potential_one_launch(tdt, tol):
     inf = VAEInference(None, lst, z, 1, np.arange(n) / n, np.zeros(n), [1, 5, 9], {}, dtype=tdt)
     Z, u = rng.standard_normal((7, z)), np.full(7, np.log(0.1))
     assert rel(inf.potential_and_grad(Z, u)[0], orc.vae_potential(p, Z, u, np.zeros(n), np.array([1, 5, 9]))) < max(tol, 1e-5)
+
+
+@pytest.mark.parametrize("tdt,tol", [(torch.float64, 1e-6), (torch.float32, 2e-3)])
+def test_nuts_device_transition_matches_the_torch_sampler(tdt, tol):
+    """gpvae_nuts_op (the NUTS transition as HIP kernels, one wave per chain) against gp_vae_amd.nuts.nuts (the
+    same algorithm as torch operations) on the same normals and uniforms: the same trees, proposals and
+    adaptation — positions agree to rounding over warm-up and sampling (few iterations: trajectories are
+    chaotic, a rounding difference may eventually flip a tree decision), ragged D (lanes stride the coordinates),
+    a potential with divergences in it, and a chain's numbers do not depend on its batch."""
+    from gp_vae_amd.nuts import nuts, nuts_device, uniforms_per_iteration
+    rng = np.random.default_rng(4)
+    for Cn, D, depth in ((7, 3, 4), (5, 70, 5), (33, 130, 3)):
+        mu = torch.tensor(rng.standard_normal(D), dtype=tdt, device=DEV)
+        sd = torch.tensor(np.exp(rng.uniform(-1.5, 1.0, D)), dtype=tdt, device=DEV)
+        calls = [0]
+
+        def pot(q):
+            calls[0] += 1
+            r = (q - mu) / sd
+            U = 0.5 * (r * r).sum(1) + 0.05 * (r ** 4).sum(1)   # not Gaussian: energy errors, some divergence early
+            return U, r / sd + 0.2 * r ** 3 / sd
+        K = uniforms_per_iteration(depth)
+
+        def noise(rows):
+            def fn(it):
+                g = torch.Generator().manual_seed(77 + it)
+                z = torch.randn((Cn, D), dtype=torch.float64, generator=g).to(DEV, tdt)
+                u = torch.rand((Cn, K), dtype=torch.float64, generator=g).to(DEV, tdt)
+                return z[rows].contiguous(), u[rows].contiguous()
+            return fn
+        q0 = torch.tensor(rng.standard_normal((Cn, D)), dtype=tdt, device=DEV)
+        allr = torch.arange(Cn, device=DEV)
+        its = (6, 4) if tdt == torch.float32 else (25, 10)
+        a, ia = nuts(pot, q0, its[0], its[1], max_tree_depth=depth, step_size=0.3, noise_fn=noise(allr))
+        b, ib = nuts_device(pot, q0, its[0], its[1], max_tree_depth=depth, step_size=0.3, noise_fn=noise(allr))
+        assert a.shape == b.shape == (its[1], Cn, D)
+        err = ((a - b).abs().max() / a.abs().max()).item()
+        assert err < tol, (Cn, D, depth, err)
+        assert torch.allclose(ia["step_size"], ib["step_size"], rtol=max(tol, 1e-6))
+        assert torch.allclose(ia["leapfrogs_per_iteration"], ib["leapfrogs_per_iteration"]) and ia["divergent"] == ib["divergent"]
+        sub = torch.tensor([1, Cn - 1], device=DEV)
+        c, _ = nuts_device(pot, q0[sub], its[0], its[1], max_tree_depth=depth, step_size=0.3, noise_fn=noise(sub))
+        # (not bit for bit here: torch's own row sums inside this test potential change their order with the batch
+        # shape; with the library's potentials the equality is exact — test_regression_seams_and_chain_sharding)
+        assert ((c - b[:, sub]).abs().max() / b.abs().max()).item() < tol
