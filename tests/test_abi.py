@@ -105,6 +105,10 @@ def test_argument_validation_of_the_round_2_entry_points():
     assert lib.gpvae_hyper_sample(null, 3, 4, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # dtype
     assert lib.gpvae_hyper_sample(null, 0, 4, 1, 2, 0, 7, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # prior id
     assert lib.gpvae_hyper_sample(null, 0, 0, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, null, null, null) == 0
+    assert lib.gpvae_nuts_op(null, 0, 9, 4, 3, 5, 0, 0, 0, 0, null) == -3       # unknown op
+    assert lib.gpvae_nuts_op(null, 0, 3, 4, 3, 5, 2, 4, 0, 0, null) == -8       # leaf 4 does not exist at depth 2
+    assert lib.gpvae_nuts_op(null, 0, 0, 4, 3, 5, 0, 0, 0, 0, null) == -11 and b"NULL" in lib.gpvae_last_error()
+    assert lib.gpvae_nuts_op(null, 0, 0, 0, 3, 5, 0, 0, 0, 0, null) == 0        # no chains: nothing to do
     assert lib.gpvae_vae_potential_supported(0, 35, 30, 10, 10) == 1 and lib.gpvae_vae_potential_supported(0, 1024, 1024, 64, 4096) == 0
     assert lib.gpvae_vae_potential(null, 0, 4, 300, 1024, 1024, 64, one, one, 65, one, None, 4096, 0.1, one, one, 65) < 0
 
