@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
-    ap.add_argument("--first-group", type=int, default=0, help="size of the first (exposed) factor group; 0 = a full group")
+    ap.add_argument("--first-group", type=str, default="", help="sizes of the first factor groups, e.g. 4,4,8 (a ramp; then full groups); empty = the engine's default")
     ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
                     help="matrix pipe of the float32 draws: bf16x3 (default where shapes allow) or the f32 MFMA")
     ap.add_argument("--force-collective", action="store_true",
@@ -348,7 +348,7 @@ def main():
     x = torch.tensor(grid_points(), device=dev)
     eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, overlap=not args.no_overlap,
                      hyper_sampler=bench_hyper, group=args.group, mfma=args.mfma,
-                     first_group=args.first_group or None)
+                     first_group=[int(v) for v in args.first_group.split(",")] if args.first_group else None)
     state = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
 
     def barrier():

@@ -260,7 +260,8 @@ class StepEngine():
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
                  hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2, mfma="auto",
                  first_group=None):
-        self.first_group = first_group
+        self.first_group = first_group  # int or sequence: sizes of the first factor groups; None: default_ramp
+        self.default_ramp = ()
         if isinstance(hyper_sampler, str) and hyper_sampler != "device":
             raise ValueError("hyper_sampler: a callable rng -> (ls, var, sigma) or 'device'")
         if kernel is not exp_kernel2:
@@ -524,12 +525,24 @@ class StepEngine():
         from .parallel import _collective_on
         self._collective = _collective_on()
         # the first group is exposed (nothing to overlap it with).  Measured on 20-step runs at C3 (ms per
-        # step): first group of 2: 1.08, 4: 1.06, 8: 1.05, a full group of 16: 0.98 — small batches factor
-        # too slowly (latency-bound launch chain) for a short first group to pay; `first_group` overrides
-        g0 = self.G
-        if self.first_group:
-            g0 = max(1, min(int(self.first_group), self.G))
-        groups = [keys[:g0]] + [keys[i:i + self.G] for i in range(g0, len(keys), self.G)]
+        # step): a full group of 16: 0.98; first group of 2 / 4 / 8: 1.08 / 1.06 / 1.05; ramps 4,4,8: 1.16,
+        # 4,8,8: 1.11, 8,8: 1.08, 2,4,8,16: 1.20; one group of 20: 1.01 — every factorisation call carries the
+        # latency of its 64 dependent panel launches whatever its batch, so fewer, fuller groups win;
+        # `first_group` (an int or a sequence of sizes) overrides
+        sched = self.first_group
+        if sched is None:
+            sched = self.default_ramp if len(keys) > self.G else ()
+        elif isinstance(sched, int):
+            sched = (sched,)
+        groups, pos = [], 0
+        for g in sched:  # the sizes of the first groups (a ramp), then full groups
+            g = max(1, min(int(g), self.G))
+            groups.append(keys[pos:pos + g])
+            pos += g
+            if pos >= len(keys):
+                break
+        groups += [keys[i:i + self.G] for i in range(pos, len(keys), self.G)]
+        groups = [g for g in groups if g]
         if self.overlap:
             for s in range(2):
                 self.ev_free[s].record(torch.cuda.current_stream())
