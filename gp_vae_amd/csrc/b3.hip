@@ -64,26 +64,28 @@ __global__ __launch_bounds__(256) void randn_b3_kernel(int64_t count, uint64_t s
   }
 }
 
-// One workgroup per 256 x 128 tile of Y, heaviest column tiles first (their k range grows with the
-// column index), plain round-robin placement over the XCDs as in draw_kernel.
+// One workgroup per 256 x 128 (WFM = 4) or 128 x 128 (WFM = 2) tile of Y, heaviest column tiles first (their k
+// range grows with the column index), plain round-robin placement over the XCDs as in draw_kernel.
+template <int WFM>
 __global__ __launch_bounds__(NTHREADS, 1) void draw_b3_kernel(
     int n, int nb, const __bf16 *L3, int64_t ldl, int64_t planeL, const __bf16 *E3, int64_t lde,
     int64_t planeE, const float *E2, int64_t lde2, const float *sigma_p, float *F, int64_t ldf,
     float *Y, int64_t ldy) {
-  __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
+  using Pipe = PipeB3T<WFM>;
+  __shared__ __align__(16) unsigned char lds[Pipe::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nrt = nb / B3_TM, nct = n / B3_TN;
+  const int nrt = nb / Pipe::TM, nct = n / B3_TN;
   const int ct = nct - 1 - (int)(blockIdx.x / nrt), rt = (int)(blockIdx.x % nrt);
-  const int64_t m0 = (int64_t)rt * B3_TM, c0 = (int64_t)ct * B3_TN;
+  const int64_t m0 = (int64_t)rt * Pipe::TM, c0 = (int64_t)ct * B3_TN;
   const int kend = (ct + 1) * B3_TN;
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (32 * WFM), wn = (wave & 1) * 64;
 
-  PipeB3 P;
+  Pipe P;
   P.init(E3 + m0 * lde, lde, planeE, L3 + c0 * ldl, ldl, planeL, tid, wm, wn);
 #pragma unroll
-  for (int i = 0; i < PipeB3::WFM; ++i)
+  for (int i = 0; i < Pipe::WFM; ++i)
 #pragma unroll
-    for (int j = 0; j < PipeB3::WFN; ++j)
+    for (int j = 0; j < Pipe::WFN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) P.acc[i][j][e] = 0.f;
   P.run(lds, 0, kend);
@@ -95,16 +97,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void draw_b3_kernel(
   if (Y != nullptr) ioy.init(Y + rw * ldy + cw, ldy, lane);
   if (E2 != nullptr) ioe.init(E2 + rw * lde2 + cw, lde2, lane);
 #pragma unroll
-  for (int fm = 0; fm < PipeB3::WFM; ++fm) {
-    float e2[PipeB3::WFN][16];
+  for (int fm = 0; fm < Pipe::WFM; ++fm) {
+    float e2[Pipe::WFN][16];
     if (E2 != nullptr) {
 #pragma unroll
-      for (int fn = 0; fn < PipeB3::WFN; ++fn)
+      for (int fn = 0; fn < Pipe::WFN; ++fn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) e2[fn][r] = ioe.load(fm, fn, r);
     }
 #pragma unroll
-    for (int fn = 0; fn < PipeB3::WFN; ++fn)
+    for (int fn = 0; fn < Pipe::WFN; ++fn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float f = P.acc[fm][fn][r];
@@ -154,7 +156,7 @@ extern "C" int gpvae_randn_b3(void *stream, int64_t count, uint64_t seed, uint64
 }
 
 extern "C" int gpvae_draw_b3_supported(int64_t n, int64_t nb) {
-  return n >= B3_TN && n % B3_TN == 0 && nb >= B3_TM && nb % B3_TM == 0 && n <= (1 << 20) && nb <= (1 << 20);
+  return n >= B3_TN && n % B3_TN == 0 && nb >= 128 && nb % 128 == 0 && n <= (1 << 20) && nb <= (1 << 20);
 }
 
 extern "C" int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3, int64_t ldl,
@@ -165,7 +167,7 @@ extern "C" int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3
   GPVAE_REQUIRE(nb >= 0, 3, "gpvae_draw_b3: nb < 0");
   if (n == 0 || nb == 0) return 0;
   GPVAE_REQUIRE(gpvae_draw_b3_supported(n, nb), 2,
-                "gpvae_draw_b3: needs n %% 128 == 0 and nb %% 256 == 0 (use gpvae_draw otherwise)");
+                "gpvae_draw_b3: needs n %% 128 == 0 and nb %% 128 == 0 (use gpvae_draw otherwise)");
   GPVAE_REQUIRE(L3 && aligned16(L3), 4, "gpvae_draw_b3: L3 NULL or not 16-byte aligned");
   GPVAE_REQUIRE(ldl >= n && ldl % 8 == 0, 5, "gpvae_draw_b3: ldl < n or not a multiple of 8");
   GPVAE_REQUIRE(planeL >= n * ldl && planeL % 8 == 0, 6, "gpvae_draw_b3: planeL < n*ldl or not a multiple of 8");
@@ -173,6 +175,8 @@ extern "C" int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3
   GPVAE_REQUIRE(lde >= n && lde % 8 == 0, 8, "gpvae_draw_b3: lde < n or not a multiple of 8");
   GPVAE_REQUIRE(planeE >= nb * lde && planeE % 8 == 0, 9, "gpvae_draw_b3: planeE < nb*lde or not a multiple of 8");
   GPVAE_REQUIRE(PipeB3::usable(lde, ldl), 8, "gpvae_draw_b3: leading dimensions too large");
+  // 128-row tiles when the 256-row tiling would leave CUs without a workgroup (or nb is not a multiple of 256)
+  const bool small = nb % B3_TM != 0 || (nb / B3_TM) * (n / B3_TN) < 256;
   if (E2) {
     GPVAE_REQUIRE(lde2 >= n, 11, "gpvae_draw_b3: lde2 < n");
     GPVAE_REQUIRE(sigma, 12, "gpvae_draw_b3: sigma is NULL with E2 given");
@@ -182,11 +186,16 @@ extern "C" int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3
   if (Y) GPVAE_REQUIRE(ldy >= n, 16, "gpvae_draw_b3: ldy < n");
   const int64_t ldmax = std::max(std::max(F ? ldf : 0, Y ? ldy : 0), E2 ? lde2 : 0);
   GPVAE_REQUIRE(128 * ldmax * 4 < ((int64_t)1 << 31), 14, "gpvae_draw_b3: output leading dimension too large");
-  const int64_t grid = (nb / B3_TM) * (n / B3_TN);
+  const int64_t grid = (nb / (small ? 128 : B3_TM)) * (n / B3_TN);
   GPVAE_REQUIRE(grid < ((int64_t)1 << 31), 3, "gpvae_draw_b3: too many tiles");
-  hipLaunchKernelGGL(draw_b3_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, (hipStream_t)stream, (int)n,
-                     (int)nb, (const __bf16 *)L3, ldl, planeL, (const __bf16 *)E3, lde, planeE,
-                     (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy);
+  if (small)
+    hipLaunchKernelGGL(draw_b3_kernel<2>, dim3((unsigned)grid), dim3(NTHREADS), 0, (hipStream_t)stream, (int)n,
+                       (int)nb, (const __bf16 *)L3, ldl, planeL, (const __bf16 *)E3, lde, planeE,
+                       (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy);
+  else
+    hipLaunchKernelGGL(draw_b3_kernel<4>, dim3((unsigned)grid), dim3(NTHREADS), 0, (hipStream_t)stream, (int)n,
+                       (int)nb, (const __bf16 *)L3, ldl, planeL, (const __bf16 *)E3, lde, planeE,
+                       (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy);
   GPVAE_CHECK_LAUNCH("gpvae_draw_b3");
   return 0;
 }

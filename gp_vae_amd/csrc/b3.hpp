@@ -43,14 +43,20 @@ __device__ __forceinline__ void split3_bf16(float v, __bf16 &h, __bf16 &m, __bf1
   l = (__bf16)(r1 - (float)m);
 }
 
-struct PipeB3 {
-  static constexpr int WFM = 4, WFN = 2;  // 32 x 32 MFMA tiles per wave: 128 x 64
+// WFM_ = 4: the 256 x 128 tile described above.  WFM_ = 2: a 128 x 128 tile (wave tiles 64 x 64, 99.8 KB of
+// LDS) for problems with fewer 256-row tiles than CUs — half the MFMAs per k-tile against two thirds of the
+// operand bytes, but twice the workgroups.
+template <int WFM_> struct PipeB3T {
+  static constexpr int WFM = WFM_, WFN = 2;  // 32 x 32 MFMA tiles per wave: (32 WFM) x 64
+  static constexpr int TM = 64 * WFM;        // rows of the A operand per workgroup
   static constexpr int PAD = 32;
-  static constexpr int CPA = B3_TM * 16 + PAD, CPB = B3_TN * 16 + PAD;  // bytes per (plane, chunk)
+  static constexpr int CPA = TM * 16 + PAD, CPB = B3_TN * 16 + PAD;  // bytes per (plane, chunk)
   static constexpr int A_BYTES = 12 * CPA, STAGE = 12 * (CPA + CPB);
   static constexpr int LDS_BYTES = 2 * STAGE;
-  static constexpr int NQA = 12, NQB = 6;  // 16-byte vectors per thread and k-tile
-  static constexpr int LEAD = 6;
+  static constexpr int NQA = 3 * WFM, NQB = 6;  // 16-byte vectors per thread and k-tile
+  static constexpr int NRD = 3 * (WFM + WFN);   // fragment reads per k16 step
+  static constexpr int NMF = 6 * WFM * WFN;     // MFMAs per k16 step
+  static constexpr int LEAD = WFM == 4 ? 6 : 0;
 
   i32x4_t pre[NQA + NQB];
   bf16x8_t fa[2][3][WFM], fb[2][3][WFN];
@@ -81,13 +87,13 @@ struct PipeB3 {
   }
   // operand tiles need rows within 2 GiB of the tile's first row
   __host__ __device__ static bool usable(int64_t lda, int64_t ldb) {
-    return (int64_t)B3_TM * lda * 2 < ((int64_t)1 << 31) && (int64_t)B3_TN * ldb * 2 < ((int64_t)1 << 31);
+    return (int64_t)TM * lda * 2 < ((int64_t)1 << 31) && (int64_t)B3_TN * ldb * 2 < ((int64_t)1 << 31);
   }
 
   __device__ __forceinline__ void gload(int k0) {
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
-      pre[q] = raw_buffer_load_b128(rsA[q >> 2], voffA, (q & 3) * 64 * lda2 + k0 * 2, 0);
+      pre[q] = raw_buffer_load_b128(rsA[q / WFM], voffA, (q % WFM) * 64 * lda2 + k0 * 2, 0);
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
       pre[NQA + q] = raw_buffer_load_b128(rsB[q >> 1], voffB, (q & 1) * 64 * ldb2 + k0 * 2, 0);
@@ -95,7 +101,7 @@ struct PipeB3 {
   template <int BUF> __device__ __forceinline__ void lstore(unsigned char *lds) {
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
-      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_a + (q >> 2) * 4 * CPA + (q & 3) * 1024) = pre[q];
+      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_a + (q / WFM) * 4 * CPA + (q % WFM) * 1024) = pre[q];
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
       *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_b + (q >> 1) * 4 * CPB + (q & 1) * 1024) = pre[NQA + q];
@@ -134,26 +140,26 @@ struct PipeB3 {
     if (HAS2) gload(k0 + 2 * B3_BK);
     mma_sub<0>();
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }  // MFMA, DS read
-    GPVAE_SGB(0x008, LEAD);
+    for (int i = 0; i < NRD; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }  // MFMA, DS read
+    if (LEAD > 0) GPVAE_SGB(0x008, LEAD);
     if (HAS1) {
 #pragma unroll
-      for (int i = 0; i < 18; ++i) {
+      for (int i = 0; i < NQA + NQB; ++i) {
         GPVAE_SGB(0x008, 1);
         GPVAE_SGB(0x200, 1);            // DS write
         if (HAS2) GPVAE_SGB(0x020, 1);  // VMEM read
       }
     }
-    GPVAE_SGB(0x008, 48);
+    GPVAE_SGB(0x008, NMF);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (HAS1) read_sub<NXT, 0>(lds);
     mma_sub<1>();
     if (HAS1) {
 #pragma unroll
-      for (int i = 0; i < 18; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }
+      for (int i = 0; i < NRD; ++i) { GPVAE_SGB(0x008, 1); GPVAE_SGB(0x100, 1); }
     }
-    GPVAE_SGB(0x008, 48);
+    GPVAE_SGB(0x008, NMF);
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef GPVAE_SGB
@@ -175,5 +181,6 @@ struct PipeB3 {
     tile<1, false, false>(lds, k0 + B3_BK);
   }
 };
+using PipeB3 = PipeB3T<4>;
 
 }  // namespace gpvae

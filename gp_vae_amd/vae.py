@@ -309,7 +309,7 @@ class StepEngine():
         self.b3 = (mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
                    and ops.potrf_b3_supported(n))
         if mfma == "bf16x3" and not self.b3:
-            raise GpvaeError("bf16x3 draws need float32, n % 256 == 0, n >= 512 and batch_size % 256 == 0")
+            raise GpvaeError("bf16x3 draws need float32, n % 256 == 0, n >= 512 and batch_size % 128 == 0")
         if self.b3:
             self.E3 = torch.empty((3, B, n), dtype=torch.bfloat16, device=dev)
             self.L3buf = [torch.empty((G, 3, n, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]

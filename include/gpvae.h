@@ -133,8 +133,9 @@ int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t 
  *                    as b3 planes (the f32 array is never materialised); count % 4 == 0.
  *   gpvae_draw_b3    F = E L^T, Y = F + sigma*E2 from b3 operands: L3 [n, ldl] (zeros above the
  *                    diagonal), E3 [nb, lde]; E2, F, Y as in gpvae_draw (f32).  Needs n % 128 == 0,
- *                    nb % 256 == 0 (gpvae_draw_b3_supported); leading dimensions and plane strides
- *                    multiples of 8, bases 16-byte aligned.  Bound: bf16 MFMA (6 n^2 nb flop issued).
+ *                    nb % 128 == 0 (gpvae_draw_b3_supported; 256 x 128 tiles, 128 x 128 ones when those
+ *                    would leave CUs idle); leading dimensions and plane strides multiples of 8, bases
+ *                    16-byte aligned.  Bound: bf16 MFMA (6 n^2 nb flop issued).
  *   gpvae_potrf_b3   gpvae_potrf(GPVAE_F32, no extra rows) that ALSO leaves the factor as b3 planes
  *                    L3 [batch][3][n, ld3] (zeros wherever gpvae_draw_b3 reads above the diagonal):
  *                    the panel launches write the planes as they go and the bf16 x 3 trailing updates

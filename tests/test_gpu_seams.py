@@ -333,7 +333,8 @@ def test_b3_planes_and_draw():
     E = ops.randn((256, 384), torch.float32, DEV, seed=12345, stream_id=7)
     assert torch.equal(E3.float().sum(0), E)
     assert ops.draw_b3_supported(4096, 4096) and not ops.draw_b3_supported(300, 100) and not ops.draw_b3_supported(4096, 100)
-    for n, nb in ((128, 256), (384, 256), (1024, 512)):
+    # 128-row tiles (fewer than 256 tiles of 256 rows, or nb not a multiple of 256) and 256-row tiles (the last case)
+    for n, nb in ((128, 256), (384, 256), (1024, 512), (256, 128), (512, 384), (2048, 4096)):
         Lh = np.tril(rng.standard_normal((n, n))) * 0.1
         E2h = rng.standard_normal((nb, n))
         L = torch.tensor(Lh, dtype=torch.float32, device=DEV) + torch.triu(torch.full((n, n), 5.0, device=DEV), 1)
