@@ -38,6 +38,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_F64_MFMA_TFLOPS = 78.6   # dense f64 matrix peak
 PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
+# what v_mfma_f32_32x32x16_bf16 sustains on this chip with random operand bits and no memory traffic at all
+# (tools/ub_mfma_power.hip, profiles/r02_mfma_power.txt; 2.46 PFLOP/s with constant operands): power management
+SUSTAINED_BF16_MFMA_RANDOM_TFLOPS = 1810.0
 GRID = 64
 N = GRID * GRID
 B = 4096
@@ -410,6 +413,8 @@ def main():
                     "avg_launch_ms": draw_ms, "flop_per_launch": 6 * flop, "algorithmic_flop_per_launch": flop,
                     "f32_equivalent_tflops": f32_equiv,
                     "f32_equivalent_frac_of_f32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS if f32_equiv else None}
+            roof["mfma_only_sustained_tflops_random_operands"] = SUSTAINED_BF16_MFMA_RANDOM_TFLOPS
+            roof["frac_of_mfma_only_sustained"] = 6 * f32_equiv / SUSTAINED_BF16_MFMA_RANDOM_TFLOPS if f32_equiv else None
             if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
                 roof["avg_launch_ms_alone"] = draw_alone_ms
                 roof["frac_alone"] = 6 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
