@@ -383,7 +383,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_fwd_kernel(VaeDims<T> d, con
 template <typename T, int RB>
 __global__ __launch_bounds__(NTHREADS) void dec_mid_bwd_kernel(VaeDims<T> d, const T *dec_params,
                                                                const T *D1, const T *D2,
-                                                               const T *dD2, T *dZ) {
+                                                               const T *dD2s, int nsD, int64_t slabD,
+                                                               T *dZ) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int mx = max(d.h0, max(d.h1, d.z));
   T *gA = reinterpret_cast<T *>(smem_raw);
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_mid_bwd_kernel(VaeDims<T> d, con
   const int rows = (int)((d.B - s0 < RB) ? d.B - s0 : RB);
   for (int idx = tid; idx < RB * h0; idx += NTHREADS) {
     const int r = idx / h0, j = idx % h0;
-    gA[idx] = (r < rows && D2[(s0 + r) * h0 + j] > T(0)) ? dD2[(s0 + r) * h0 + j] : T(0);
+    gA[idx] = (r < rows && D2[(s0 + r) * h0 + j] > T(0)) ? slab_sum_at<T>(dD2s, nsD, slabD, (s0 + r) * h0 + j) : T(0);
   }
   __syncthreads();
   dense_bwd_in<T, RB>(gA, h0, V2, h1, gB, tid);
@@ -908,13 +909,15 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   return 0;
 }
 
+static inline int decoder_vjp_splits(int64_t C, int64_t n, int h0) { return pick_splitk(cdiv(C, GBM) * cdiv(h0, GBN), n); }
+
 template <typename T>
 static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, int h1, int z,
                        const void *dec_v, const void *Z_v, const void *dF_v, void *out_v,
                        void *work_v) {
   const T *dec = (const T *)dec_v;
   const T *V3 = dec + (int64_t)z * h1 + h1 + (int64_t)h1 * h0 + h0, *c3 = V3 + (int64_t)h0 * n;
-  T *D1 = (T *)work_v, *D2 = D1 + C * h1, *dD2 = D2 + C * h0;
+  T *D1 = (T *)work_v, *D2 = D1 + C * h1, *dD2 = D2 + C * h0, *SD = dD2 + C * h0;  // SD: k-slices of dF V3^T
   VaeDims<T> dims{C, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
   // as in run_vae_elbo: per-sample-block kernels for the reference's small heads, tile products when wide
@@ -938,15 +941,16 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
     launch_gemm<T, true, false, EPI_BIAS>(st, g, 1);
   } else {  // dD2 = dF V3^T, then back through the head
     GemmArgs<T> g{};
-    g.A = (const T *)dF_v; g.lda = n; g.B = V3; g.ldb = n; g.C = dD2; g.ldc = h0;
+    // k-slices stored side by side and added in slice order by the consumer: no float atomics, no clearing
+    g.A = (const T *)dF_v; g.lda = n; g.B = V3; g.ldb = n; g.C = SD; g.ldc = h0; g.slab = C * h0;
     g.M = C; g.N = h0; g.K = n; g.a_ones_row = -1;
     g.vec_a = kc_vec_ok<T>(dF_v, n); g.vec_b = kc_vec_ok<T>(V3, n);
-    (void)hipMemsetAsync(dD2, 0, sizeof(T) * C * h0, st);
-    launch_gemm<T, true, true, EPI_ATOMIC>(st, g, pick_splitk(cdiv(C, GBM) * cdiv(h0, GBN), n));
+    const int ns = launch_gemm<T, true, true, EPI_ATOMIC>(st, g, decoder_vjp_splits(C, n, h0));
     if (!wide) {
       GPVAE_RB_SWITCH(rb, hipLaunchKernelGGL((dec_mid_bwd_kernel<T, RB>), dim3(nblk), dim3(NTHREADS), shm,
-                                             st, dims, dec, D1, D2, dD2, (T *)out_v));
+                                             st, dims, dec, D1, D2, (const T *)SD, ns, C * h0, (T *)out_v));
     } else {
+      launch_slab_sum<T>(st, dD2, SD, C * h0, ns, C * h0);
       hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(C * h0)), dim3(NTHREADS), 0, st, C * h0, dD2, D2);
       dense_gemm_t<T>(st, dD2, C, h0, V2, h1, D1, 0, D1);  // (dG2 V2^T) (D1 > 0), over D1
       dense_gemm_t<T>(st, D1, C, h1, V1, z, (T *)out_v, 0, (const T *)nullptr);
@@ -1176,8 +1180,12 @@ extern "C" int gpvae_encoder_fwd(void *stream, int dtype, int64_t B, int64_t n, 
 
 extern "C" int64_t gpvae_decoder_workspace_bytes(int dtype, int64_t chains, int64_t n, int h0,
                                                  int h1, int z) {
-  (void)n; (void)z;
-  return chains * ((int64_t)h1 + 2 * (int64_t)h0) * (dtype == GPVAE_F64 ? 8 : 4) + 256;
+  (void)z;
+  // D1 | D2 | dD2 | the k-slices of dF V3^T (the VJP's one n-sized product)
+  const int64_t ns = chains > 0 && n > 0 ? (dtype == GPVAE_F64 ? gemm_slices<double>(n, decoder_vjp_splits(chains, n, h0))
+                                                                : gemm_slices<float>(n, decoder_vjp_splits(chains, n, h0)))
+                                         : 1;
+  return chains * ((int64_t)h1 + (2 + ns) * (int64_t)h0) * (dtype == GPVAE_F64 ? 8 : 4) + 256;
 }
 
 extern "C" int gpvae_decoder_fwd(void *stream, int dtype, int64_t chains, int64_t n, int h0, int h1,
@@ -1294,7 +1302,7 @@ extern "C" int gpvae_decoder_vjp_static(void *stream, int dtype, int64_t chains,
   GPVAE_REQUIRE(dec_params && Z && dF && dZ, 8, "gpvae_decoder_vjp_static: NULL pointer");
   const int64_t need = gpvae_decoder_workspace_bytes(dtype, chains, n, h0, h1, z);
   GPVAE_REQUIRE(need <= (int64_t)GPVAE_STATIC_SCRATCH_BYTES, 3,
-                "gpvae_decoder_vjp_static: chains * (h1 + 2 h0) * sizeof(T) = %lld bytes exceeds the static "
+                "gpvae_decoder_vjp_static: the scratch this call needs (%lld bytes) exceeds the static "
                 "scratch of %lld bytes; use gpvae_decoder_vjp with a caller workspace",
                 (long long)need, (long long)GPVAE_STATIC_SCRATCH_BYTES);
   void *work = nullptr;

@@ -339,7 +339,8 @@ int gpvae_nuts_op(void *stream, int dtype, int op, int64_t C, int64_t D, int max
 /* ---- the same VJP with no workspace argument and no allocation ------------------------------------
  * No counterpart in the reference.  For callers that cannot allocate or carry a workspace: code
  * under HIP graph capture, tight MCMC / serving loops, harnesses that forbid hipMalloc.  Same kernels
- * and results as gpvae_decoder_vjp; the scratch (chains * (h1 + 2 h0) elements + 256 bytes) lives in
+ * and results as gpvae_decoder_vjp; the scratch (gpvae_decoder_workspace_bytes: chains * (h1 + (2 + s) h0)
+ * elements + 256 bytes, s <= 32 the number of k-slices of its one n-sized product) lives in
  * a static device array of GPVAE_STATIC_SCRATCH_BYTES = 4 MiB per GPU, held until the process ends.  Larger problems are rejected with -3 and a message.  Calls on one GPU share that
  * array: calls that overlap on one GPU (two streams, two threads) race — serialise them.  The first
  * call on each device looks the array's address up (hipGetSymbolAddress): make it outside a capture. */
