@@ -722,14 +722,16 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
   const bool failed = (flags & GPVAE_POTRF_NAN_ON_FAIL) && info[b] != 0;
   const bool zero_up = flags & GPVAE_POTRF_ZERO_UPPER;
   const int64_t i0 = (int64_t)blockIdx.y * NB;
-  // without flags only the diagonal blocks are touched: one 64-thread block per diagonal block
+  // without flags only the diagonal blocks are touched: one 64 x 4-thread block per diagonal block
+  // (threadIdx.y strides the rows; with flags blockDim.y == 1)
   const int64_t j = flags ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : i0 + threadIdx.x;
+  const int ry = threadIdx.y, rs = blockDim.y;
   if (j >= n) return;
   const int64_t i1 = (i0 + NB < n) ? i0 + NB : n;
   const bool in_diag = j >= i0 && j < i0 + NB;  // this column crosses the strip's diagonal block
   if (!failed && !in_diag && (!zero_up || j < i0)) return;  // nothing to do for this column strip
   const T *l11 = dwork + ((int64_t)b * (npad / NB) + blockIdx.y) * (NB * NB);
-  for (int64_t i = i0; i < i1; ++i) {
+  for (int64_t i = i0 + ry; i < i1; i += rs) {
     if (failed) Ab[i * lda + j] = dnan<T>();
     else if (in_diag) Ab[i * lda + j] = l11[(i - i0) * NB + (j - i0)];  // L11 (upper part is zero)
     else if (j > i) Ab[i * lda + j] = T(0);
@@ -741,7 +743,7 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
     if (o3.p != nullptr && o3.whole && in_diag) {
       __bf16 *q = o3.p + (int64_t)b * o3.stride;
       const bool even = (blockIdx.y & 1) == 0 && j + NB < n;
-      for (int64_t i = i0; i < i1; ++i) {
+      for (int64_t i = i0 + ry; i < i1; i += rs) {
         __bf16 hh, mm, ll;
         split3_bf16(failed ? dnan<float>() : l11[(i - i0) * NB + (j - i0)], hh, mm, ll);
         q[i * o3.ld + j] = hh;
@@ -814,7 +816,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
   }
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
                      dim3(flags ? (unsigned)cdiv(n, 256) : 1u, (unsigned)cdiv(n, NB), (unsigned)batch),
-                     dim3(flags ? 256 : NB), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
+                     flags ? dim3(256) : dim3(NB, 4), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
                      flags, o3);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
