@@ -52,6 +52,13 @@ def main():
     steps = a.num_epochs * (a.num_train + a.num_test)
     print("VAE.fit: %d epochs, test loss per sample by epoch: %s" % (a.num_epochs, ["%.1f" % v for v in vae.test_loss_list]))
     print("         %.2f s, %.0f draws/s incl. evaluation" % (t_fit, steps * a.batch_size / t_fit))
+    # the reference pickles the decoder here (toy_examples.py:163-165) and reloads it for inference
+    import os
+    import tempfile
+    from gp_vae_amd.vae import load_decoder_params, save_decoder_params
+    with tempfile.TemporaryDirectory() as tmp:
+        save_decoder_params(os.path.join(tmp, "decoder.npz"), decoder_params)
+        decoder_params = load_decoder_params(os.path.join(tmp, "decoder.npz"))
 
     # ground truth: one GP draw with ls = 0.05, var = 1, observed with noise at 10 points
     draw = Predictive(gp.sample, num_samples=1)(a.seed + 7, x, ls=a.ls, var=1.0, sigma=a.noise)
