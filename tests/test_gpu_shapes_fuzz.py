@@ -258,3 +258,30 @@ def test_gp_potential_random_shapes_f64(ops):
             assert abs(dU[c, j].item() - fd) < 2e-4 * max(1.0, abs(fd)), tag + (c, j, dU[c, j].item(), fd)
         U1, dU1, _ = ops.gp_potential(xd, qd[c:c + 1], torch.tensor(y, dtype=torch.float64, device=DEV))
         assert torch.equal(U1[0], U[c]) and torch.equal(dU1[0], dU[c]), tag
+
+
+def test_potrf_b3_and_draw_b3_random_shapes(ops):
+    """The bf16 x 3 route over its supported shapes (n a multiple of 256 from 512 up; batches that straddle
+    the 8-XCD tile map; A with a padded leading dimension; draw batches that are multiples of 128 and of 256):
+    factor against LAPACK on well-conditioned SPD matrices, planes == factor, and the draw from the planes
+    against a float64 product — all at the float32 bar of the f32-MFMA kernels."""
+    rng = np.random.default_rng(29)
+    for case in range(6):
+        n = int(rng.choice([512, 768, 1024, 1536]))
+        batch = int(rng.choice([1, 2, 7, 8, 9, 17]))
+        nb = int(rng.choice([128, 256, 384, 640]))
+        A = spd(rng, batch, n)
+        Ad = padded(A, torch.float32, int(rng.choice([0, 4, 12])))
+        info, L3 = ops.potrf_b3_(Ad)
+        tag = (case, n, batch, nb)
+        assert (info == 0).all(), tag
+        for b in {0, batch // 2, batch - 1}:
+            Lo = np.linalg.cholesky(A[b])
+            Ld = torch.tril(Ad[b])
+            assert rel(Ld, Lo) < 2e-5, tag + (b, rel(Ld, Lo))
+            assert torch.equal(torch.tril(L3[b].float().sum(0)), Ld), tag  # entries are O(1): no piece underflows
+            E3 = ops.randn_b3((nb, n), DEV, seed=case, stream_id=b)
+            E2 = ops.randn((nb, n), torch.float32, DEV, seed=case, stream_id=100 + b)
+            Y = ops.draw_b3(L3[b], E3, E2, 0.25)
+            want = E3.float().sum(0).double() @ Ld.double().T + 0.25 * E2.double()
+            assert rel(Y, want.cpu().numpy()) < 1e-6, tag + (b,)
