@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--group", type=int, default=16, help="steps whose factors are built as one batch")
     ap.add_argument("--first-group", type=str, default="", help="sizes of the first factor groups, e.g. 4,4,8 (a ramp; then full groups); empty = the engine's default")
-    ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3"], default="auto",
+    ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3", "f16x2"], default="auto",
                     help="matrix pipe of the float32 draws: bf16x3 (default where shapes allow) or the f32 MFMA")
     ap.add_argument("--force-collective", action="store_true",
                     help="single GPU: create a one-rank RCCL group and run the per-step all-reduce anyway")
@@ -418,6 +418,17 @@ def main():
             if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
                 roof["avg_launch_ms_alone"] = draw_alone_ms
                 roof["frac_alone"] = 6 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+        elif getattr(eng, "h2", False):
+            # fp16 x 2 (opt-in): three fp16 piece products per float product are issued
+            roof = {"kernel": "draw_b3_kernel<NP=2> (Y = E L^T + sigma E', fp16 x 2: operands to 22 bits, f32 accumulate)",
+                    "mfma": "f16x2", "bound": "mfma", "achieved": 3 * f32_equiv if f32_equiv else None,
+                    "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 3 * f32_equiv / PEAK_BF16_MFMA_TFLOPS if f32_equiv else None, "traffic": None,
+                    "avg_launch_ms": draw_ms, "flop_per_launch": 3 * flop, "algorithmic_flop_per_launch": flop,
+                    "f32_equivalent_tflops": f32_equiv}
+            if draw_alone_ms:
+                roof["avg_launch_ms_alone"] = draw_alone_ms
+                roof["frac_alone"] = 3 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
         else:
             roof = {"kernel": "draw_kernel<float> (Y = E L^T + sigma E')", "mfma": "f32", "bound": "mfma",
                     "achieved": f32_equiv, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -443,7 +454,7 @@ def main():
                                    "full step gram+potrf+draw+ELBO fwd/bwd+Adam",
                        "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
                        "z_dim": DIMS[2], "parallelism": "dp%d" % world,
-                       "draw_mfma": "bf16x3" if eng.b3 else "f32",
+                       "draw_mfma": "bf16x3" if eng.b3 else ("f16x2" if getattr(eng, "h2", False) else "f32"),
                        "factor_stream_overlap": not args.no_overlap, "factor_group": args.group,
                        "forced_single_rank_collective": bool(args.force_collective)},
             "roofline": roof,
@@ -456,7 +467,7 @@ def main():
         if two_streams:
             out.update({"cholesky_two_streams": chol[3], "cholesky_batch64_two_streams": chol[4],
                         "cholesky_f64_two_streams": chol[5]})
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(eng.b3)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = (None, None) if getattr(eng, "h2", False) else pmc_traffic(eng.b3)
         if world == 1 and not args.no_extras:
             out.update(extras(ops, x, dev))
         if world == 1 and not args.no_cpu_baseline:

@@ -66,6 +66,9 @@ SIGNATURES = {
     "gpvae_decoder_vjp": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpvae_vae_potential_supported": (_i, [_i, _i, _i, _i, _i64]),
     "gpvae_vae_potential": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i64, _d, _vp, _vp, _i64]),
+    "gpvae_split_h2": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i64, _i, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "gpvae_randn_h2": (_i, [_vp, _i64, _u64, _u64, _vp, _i64]),
+    "gpvae_draw_h2": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "gpvae_nuts_op": (_i, [_vp, _i, _i, _i64, _i64, _i, _i, _i, _i, _i, _vp]),
     "gpvae_decoder_vjp_static": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
 }

@@ -28,6 +28,7 @@
 namespace gpvae {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int B3_TM = 256, B3_TN = 128, B3_BK = 32;
 
@@ -46,33 +47,42 @@ __device__ __forceinline__ void split3_bf16(float v, __bf16 &h, __bf16 &m, __bf1
 // WFM_ = 4: the 256 x 128 tile described above.  WFM_ = 2: a 128 x 128 tile (wave tiles 64 x 64, 99.8 KB of
 // LDS) for problems with fewer 256-row tiles than CUs — half the MFMAs per k-tile against two thirds of the
 // operand bytes, but twice the workgroups.
-template <int WFM_> struct PipeB3T {
+// NP_ = 3: three bf16 planes per operand, six piece products (above).  NP_ = 2: "fp16 x 2" — two fp16 planes
+// (11 + 11 significand bits of the operand, which the caller has scaled into fp16's range) and the three
+// products a0 b1, a1 b0, a0 b0 on v_mfma_f32_32x32x16_f16: half the matrix work; the operands are rounded to
+// 22 bits, and the measured error of a K = 4096 product is the same 8e-8 of sum|a b| as bf16 x 3's, because the
+// f32 accumulation dominates both (tools/ub_bf16x3.hip).  Planes are 2-byte elements either way.
+template <int WFM_, int NP_ = 3> struct PipeB3T {
   static constexpr int WFM = WFM_, WFN = 2;  // 32 x 32 MFMA tiles per wave: (32 WFM) x 64
+  static constexpr int NP = NP_;
+  static constexpr int NPROD = NP == 3 ? 6 : 3;
   static constexpr int TM = 64 * WFM;        // rows of the A operand per workgroup
   static constexpr int PAD = 32;
   static constexpr int CPA = TM * 16 + PAD, CPB = B3_TN * 16 + PAD;  // bytes per (plane, chunk)
-  static constexpr int A_BYTES = 12 * CPA, STAGE = 12 * (CPA + CPB);
+  static constexpr int A_BYTES = NP * 4 * CPA, STAGE = NP * 4 * (CPA + CPB);
   static constexpr int LDS_BYTES = 2 * STAGE;
-  static constexpr int NQA = 3 * WFM, NQB = 6;  // 16-byte vectors per thread and k-tile
-  static constexpr int NRD = 3 * (WFM + WFN);   // fragment reads per k16 step
-  static constexpr int NMF = 6 * WFM * WFN;     // MFMAs per k16 step
-  static constexpr int LEAD = WFM == 4 ? 6 : 0;
+  static constexpr int NQA = NP * WFM, NQB = NP * 2;  // 16-byte vectors per thread and k-tile
+  static constexpr int NRD = NP * (WFM + WFN);        // fragment reads per k16 step
+  static constexpr int NMF = NPROD * WFM * WFN;       // MFMAs per k16 step
+  static constexpr int LEAD = (WFM == 4 && NP == 3) ? 6 : 0;
 
   i32x4_t pre[NQA + NQB];
-  bf16x8_t fa[2][3][WFM], fb[2][3][WFN];
+  i32x4_t fa[2][NP][WFM], fb[2][NP][WFN];  // fragments: 8 two-byte elements each
   f32x16 acc[WFM][WFN];
-  i32x4_t rsA[3], rsB[3];  // per plane: resource at the tile's first row
+  i32x4_t rsA[NP], rsB[NP];  // per plane: resource at the tile's first row
   int voffA, voffB;        // per-lane byte offset of the loads (row tid/4, chunk tid%4)
   int lda2, ldb2;          // row strides in bytes (scalar)
   int wr_a, wr_b;          // per-lane LDS byte offsets of the tile writes
   int rd_a, rd_b;          // per-lane LDS byte offsets of the fragment reads
 
   // A3 / B3: plane 0 of the operand at the tile's first row and k = 0; planes psA / psB ELEMENTS apart
-  __device__ __forceinline__ void init(const __bf16 *A3, int64_t lda, int64_t psA, const __bf16 *B3,
+  template <typename E>
+  __device__ __forceinline__ void init(const E *A3, int64_t lda, int64_t psA, const E *B3,
                                        int64_t ldb, int64_t psB, int tid, int wm, int wn) {
+    static_assert(sizeof(E) == 2, "planes of two-byte elements");
     const int lane = tid & 63, r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
       rsA[p] = make_buffer_rsrc(A3 + p * psA);
       rsB[p] = make_buffer_rsrc(B3 + p * psB);
     }
@@ -108,26 +118,35 @@ template <int WFM_> struct PipeB3T {
   }
   template <int BUF, int S> __device__ __forceinline__ void read_sub(const unsigned char *lds) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int f = 0; f < WFM; ++f)
-        fa[S][p][f] = *reinterpret_cast<const bf16x8_t *>(lds + BUF * STAGE + rd_a + (p * 4 + 2 * S) * CPA + f * 512);
+        fa[S][p][f] = *reinterpret_cast<const i32x4_t *>(lds + BUF * STAGE + rd_a + (p * 4 + 2 * S) * CPA + f * 512);
 #pragma unroll
       for (int f = 0; f < WFN; ++f)
-        fb[S][p][f] = *reinterpret_cast<const bf16x8_t *>(lds + BUF * STAGE + rd_b + (p * 4 + 2 * S) * CPB + f * 512);
+        fb[S][p][f] = *reinterpret_cast<const i32x4_t *>(lds + BUF * STAGE + rd_b + (p * 4 + 2 * S) * CPB + f * 512);
     }
   }
   template <int S> __device__ __forceinline__ void mma_sub() {
     // piece products smallest first; consecutive MFMAs go to DIFFERENT accumulators (a dependent
     // back-to-back pair on one accumulator would wait for the first one's last pass)
-    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};  // NP == 3
+    constexpr int QA[3] = {0, 1, 0}, QB[3] = {1, 0, 0};                    // NP == 2
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NPROD; ++q)
 #pragma unroll
       for (int fm = 0; fm < WFM; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < WFN; ++fn)
-          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][PA[q]][fm], fb[S][PB[q]][fn], acc[fm][fn], 0, 0, 0);
+        for (int fn = 0; fn < WFN; ++fn) {
+          if constexpr (NP == 3)
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[S][PA[q]][fm]),
+                                                                  __builtin_bit_cast(bf16x8_t, fb[S][PB[q]][fn]),
+                                                                  acc[fm][fn], 0, 0, 0);
+          else
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, fa[S][QA[q]][fm]),
+                                                                 __builtin_bit_cast(f16x8_t, fb[S][QB[q]][fn]),
+                                                                 acc[fm][fn], 0, 0, 0);
+        }
   }
 #define GPVAE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   // k-tile in buffer CUR.  HAS1 / HAS2: tiles t+1 / t+2 exist.

@@ -237,6 +237,55 @@ def randn(shape, dtype=torch.float32, device="cuda", seed=0, stream_id=0, out=No
     return out
 
 
+# ---- fp16 x 2: the draw on two fp16 planes per operand (opt-in; include/gpvae.h) --------------------------
+def split_h2(X, bound, lower=False, out=None, inv_scale=None):
+    """float32 [rows, cols] or [batch, rows, cols] -> (planes [.., 2, rows, cols] fp16 of X * 2^e, inv_scale [batch]
+    = 2^-e); `bound`: per-matrix upper bound of |entries| (scalar or [batch] tensor)."""
+    _dev(X, out)
+    X3 = X if X.dim() == 3 else X.unsqueeze(0)
+    if X3.dtype != torch.float32 or X3.stride(2) != 1:
+        raise GpvaeError("split_h2: X must be float32 with unit column stride")
+    batch, rows, cols = X3.shape
+    if out is None:
+        out = torch.empty((batch, 2, rows, cols), dtype=torch.float16, device=X.device)
+    o = out.view(batch, 2, rows, cols)
+    b = bound if isinstance(bound, torch.Tensor) else torch.full((batch,), float(bound), device=X.device)
+    b = b.to(device=X.device, dtype=torch.float32).reshape(-1).contiguous()
+    if b.numel() != batch:
+        raise GpvaeError("split_h2: one bound per matrix")
+    if inv_scale is None:
+        inv_scale = torch.empty(batch, dtype=torch.float32, device=X.device)
+    check(_lib.load().gpvae_split_h2(_stream(), rows, cols, batch, _p(X3), X3.stride(1), X3.stride(0), int(bool(lower)),
+                                     _p(b), _p(o), o.stride(2), o.stride(1), o.stride(0), _p(inv_scale)), "gpvae_split_h2")
+    return (o if X.dim() == 3 else o[0]), inv_scale
+
+
+def randn_h2(shape, device="cuda", seed=0, stream_id=0, out=None):
+    """The float32 normals of randn(shape, seed, stream_id), times 2^12, as fp16 planes [2, *shape]."""
+    if out is None:
+        out = torch.empty((2,) + tuple(shape), dtype=torch.float16, device=device)
+    _dev(out)
+    if not out.is_contiguous() or out.dtype != torch.float16 or out.shape[0] != 2:
+        raise GpvaeError("randn_h2: out must be a contiguous float16 [2, ...] tensor")
+    count = out[0].numel()
+    check(_lib.load().gpvae_randn_h2(_stream(), count, int(seed), int(stream_id), _p(out), count), "gpvae_randn_h2")
+    return out
+
+
+def draw_h2(L2, inv_scale, E2h, E2=None, sigma=None, want_f=False, out=None):
+    """Y = E L^T (+ sigma*E2) from fp16 x 2 operands: L2 [2,n,n] with its inv_scale [1] (split_h2), E2h [2,nb,n]
+    (randn_h2), E2 [nb,n] float32.  Returns Y or (F, Y), float32."""
+    _dev(L2, E2h, E2, out, inv_scale)
+    n, nb = L2.shape[1], E2h.shape[1]
+    Y = torch.empty((nb, n), dtype=torch.float32, device=L2.device) if out is None else out
+    F = torch.empty((nb, n), dtype=torch.float32, device=L2.device) if want_f else None
+    sig = scalar(sigma, Y) if E2 is not None else None
+    check(_lib.load().gpvae_draw_h2(_stream(), n, nb, _p(L2), L2.stride(1), L2.stride(0), _p(inv_scale), _p(E2h),
+                                    E2h.stride(1), E2h.stride(0), _p(E2), E2.stride(0) if E2 is not None else 0,
+                                    _p(sig), _p(F), n if want_f else 0, _p(Y), Y.stride(0)), "gpvae_draw_h2")
+    return (F, Y) if want_f else Y
+
+
 PRIOR_INVGAMMA, PRIOR_BETA = 0, 1
 
 

@@ -303,17 +303,28 @@ class StepEngine():
         self.pwork = [torch.empty(max(16, wbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         # float32 draws run on the bf16 matrix pipe when the shapes allow ("bf16 x 3": exact 3-way bf16
         # split of both operands, six piece products, f32 accumulation — float32-accurate at 2.5x the f32
-        # MFMA rate, csrc/b3.hpp): E is generated straight as bf16 planes, L is split on the factor stream
-        if mfma not in ("auto", "f32", "bf16x3"):
-            raise ValueError("mfma must be 'auto', 'f32' or 'bf16x3'")
+        # MFMA rate, csrc/b3.hpp): E is generated straight as bf16 planes, L is split on the factor stream.
+        # mfma="f16x2" (opt-in): the draw on two fp16 planes per operand — half the matrix work of bf16 x 3; the
+        # operands are rounded to 22 bits, measured errors are those of the f32-MFMA kernel or below
+        # (include/gpvae.h, tests/test_gpu_seams.py::test_h2_planes_and_draw).  The factor comes from plain
+        # gpvae_potrf and is split on the factor stream.
+        if mfma not in ("auto", "f32", "bf16x3", "f16x2"):
+            raise ValueError("mfma must be 'auto', 'f32', 'bf16x3' or 'f16x2'")
         self.b3 = (mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
                    and ops.potrf_b3_supported(n))
-        if mfma == "bf16x3" and not self.b3:
-            raise GpvaeError("bf16x3 draws need float32, n % 256 == 0, n >= 512 and batch_size % 128 == 0")
+        if mfma in ("bf16x3", "f16x2") and not self.b3:
+            raise GpvaeError("%s draws need float32, n %% 256 == 0, n >= 512 and batch_size %% 128 == 0" % mfma)
+        self.h2 = self.b3 and mfma == "f16x2"
+        if self.h2:
+            self.b3 = False
+            self.Eh = torch.empty((2, B, n), dtype=torch.float16, device=dev)
+            self.L2buf = [torch.empty((G, 2, n, n), dtype=torch.float16, device=dev) for _ in range(2)]
+            self.L2inv = [torch.empty(G, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.L2bound = [torch.empty(G, dtype=torch.float32, device=dev) for _ in range(2)]
         if self.b3:
             self.E3 = torch.empty((3, B, n), dtype=torch.bfloat16, device=dev)
             self.L3buf = [torch.empty((G, 3, n, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]
-        self.E = None if self.b3 else torch.empty((B, n), dtype=dtype, device=dev)
+        self.E = None if (self.b3 or self.h2) else torch.empty((B, n), dtype=dtype, device=dev)
         self.E2 = torch.empty((B, n), dtype=dtype, device=dev)
         # two draw buffers: step t+1 is drawn while step t's gradient all-reduce is in flight
         self.Ybuf = [torch.empty((B, n), dtype=dtype, device=dev) for _ in range(2)]
@@ -345,6 +356,10 @@ class StepEngine():
         if self.b3:
             self._pL3 = [[vp(self.L3buf[s].data_ptr() + i * 3 * n * n * 2) for i in range(G)] for s in range(2)]
             self._pE3 = vp(self.E3.data_ptr())
+        elif self.h2:
+            self._pL2 = [[vp(self.L2buf[s].data_ptr() + i * 2 * n * n * 2) for i in range(G)] for s in range(2)]
+            self._pL2inv = [[vp(self.L2inv[s].data_ptr() + i * 4) for i in range(G)] for s in range(2)]
+            self._pEh = vp(self.Eh.data_ptr())
         else:
             self._pE = vp(self.E.data_ptr())
         self._pE2 = vp(self.E2.data_ptr())
@@ -402,6 +417,12 @@ class StepEngine():
                 check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
                                       0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
                       "gpvae_potrf")
+            if self.h2:
+                # |L_ij| <= sqrt(K_ii) = sqrt(var + jitter): the bound the fp16 scaling is chosen from
+                torch.sqrt(hd[0] + float(self.jitter), out=self.L2bound[slot])
+                check(lib.gpvae_split_h2(_stream(), self.n, self.n, g, _p(K), self.ld, self.n * self.ld, 1,
+                                         _p(self.L2bound[slot]), _p(self.L2buf[slot]), self.n, self.n * self.n,
+                                         2 * self.n * self.n, _p(self.L2inv[slot])), "gpvae_split_h2")
             self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
             self.ev_ready[slot].record(stream)
 
@@ -413,6 +434,8 @@ class StepEngine():
         sid = ((self.rank & 0xFF) << 56) | ((int(key[0]) & 0xFFFFFF) << 28) | ((int(key[-1]) & 0xFFFFFF) << 4)
         if self.b3:
             rc = lib.gpvae_randn_b3(h, B * n, seed, sid | 1, self._pE3, B * n)
+        elif self.h2:
+            rc = lib.gpvae_randn_h2(h, B * n, seed, sid | 1, self._pEh, B * n)
         else:
             rc = lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 1, self._pE)
         rc = rc or lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 2, self._pE2)
@@ -440,6 +463,9 @@ class StepEngine():
         if self.b3:
             rc = lib.gpvae_draw_b3(hm, n, self.B, self._pL3[slot][i], n, n * n, self._pE3, n, self.B * n,
                                    self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
+        elif self.h2:
+            rc = lib.gpvae_draw_h2(hm, n, self.B, self._pL2[slot][i], n, n * n, self._pL2inv[slot][i], self._pEh, n,
+                                   self.B * n, self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
         else:
             rc = lib.gpvae_draw(hm, self._dtc, n, self.B, self._pK[slot][i], self.ld, self._pE, n,
                                 self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)

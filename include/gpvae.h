@@ -158,6 +158,29 @@ int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3, int64_t l
                   const void *E3, int64_t lde, int64_t planeE, const void *E2, int64_t lde2,
                   const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy);
 
+/* ---- the same draw on two fp16 planes ("fp16 x 2"): half the matrix work of bf16 x 3 -----------------------
+ * Opt-in variant of gpvae_draw_b3 (gp.py:190-194, vae.py:160-162).  Each float operand x, scaled by a power of
+ * two into fp16's range, is kept as two fp16 planes h + l (11 + 11 significand bits: x is rounded to 22 bits,
+ * relative error <= 2^-22), and a product is accumulated in f32 from a0 b1 + a1 b0 + a0 b0.  Measured on a
+ * K = 4096 product: max |err| / sum|a b| = 8e-8, the same as bf16 x 3 and below the f32 MFMA's 1.4e-7 (the f32
+ * accumulation dominates); single products carry up to 5e-7 instead of 6e-8.  Not bit-compatible with the
+ * bf16 x 3 / f32 results; every f32 parity bound of the path holds (tests).
+ *   gpvae_split_h2   X [batch][rows, ldx] (f32) -> planes out2[2][...] of X * 2^e_b, e_b chosen from bound[b]
+ *                    (device array: an upper bound of |entries| of matrix b — sqrt(max diag K) for a Cholesky
+ *                    factor of K) so that nothing overflows; inv_scale[b] = 2^-e_b (device, f32) is written for
+ *                    the draw.  lower != 0 writes zeros above the diagonal.
+ *   gpvae_randn_h2   the normals of gpvae_randn(GPVAE_F32, count, seed, stream_id), times 2^12, as two planes.
+ *   gpvae_draw_h2    F = E L^T, Y = F + sigma*E2 from such planes (shapes as gpvae_draw_b3_supported); the
+ *                    accumulators are rescaled by inv_scale_L[0] * 2^-12 (exact).  Bound: fp16 MFMA
+ *                    (3 n^2 nb flop issued).                                                              */
+int gpvae_split_h2(void *stream, int64_t rows, int64_t cols, int batch, const void *X, int64_t ldx,
+                   int64_t strideX, int lower, const void *bound, void *out2, int64_t ld2, int64_t plane,
+                   int64_t stride2, void *inv_scale);
+int gpvae_randn_h2(void *stream, int64_t count, uint64_t seed, uint64_t stream_id, void *out2, int64_t plane);
+int gpvae_draw_h2(void *stream, int64_t n, int64_t nb, const void *L2, int64_t ldl, int64_t planeL,
+                  const void *inv_scale_L, const void *E2h, int64_t lde, int64_t planeE, const void *E2,
+                  int64_t lde2, const void *sigma, void *F, int64_t ldf, void *Y, int64_t ldy);
+
 /* ---- f3: hyper-prior samplers on the device -------------------------------------------------------
  * Replaces the three numpyro.sample draws of the training loop and of GP.sample
  * (src/model/vae.py:157-159, gp.py:171-176): for i in [0, count)

@@ -517,3 +517,37 @@ def test_nuts_device_transition_matches_the_torch_sampler(tdt, tol):
         # (not bit for bit here: torch's own row sums inside this test potential change their order with the batch
         # shape; with the library's potentials the equality is exact — test_regression_seams_and_chain_sharding)
         assert ((c - b[:, sub]).abs().max() / b.abs().max()).item() < tol
+
+
+def test_h2_planes_and_draw():
+    """fp16 x 2 (opt-in): the two planes hold the scaled float to 2^-22, nothing overflows at the stated bound,
+    and the draw from them meets gpvae_draw's float32 bar against the float64 oracle — error of the same size
+    as the f32-MFMA and bf16 x 3 kernels on the same inputs — over wide dynamic ranges of L and both tile sizes."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(19)
+    X = torch.tensor(rng.standard_normal((2, 130, 72)) * 10 ** rng.uniform(-4, 1, (2, 130, 72)), dtype=torch.float32, device=DEV)
+    bound = X.abs().amax(dim=(1, 2))
+    P, inv = ops.split_h2(X, bound)
+    assert P.shape == (2, 2, 130, 72) and torch.isfinite(P.float()).all()
+    back = P.float().sum(1) * inv[:, None, None]
+    err = (back - X).abs()
+    assert (err <= 2.0 ** -21 * X.abs() + 2.0 ** -38 * bound[:, None, None]).all()
+    assert (P[:, 0].float().abs().amax(dim=(1, 2)) <= 2.0 ** 14).all() and (P[:, 0].float().abs().amax(dim=(1, 2)) > 2.0 ** 12).all()
+    E2h = ops.randn_h2((256, 384), DEV, seed=12345, stream_id=7)
+    E = ops.randn((256, 384), torch.float32, DEV, seed=12345, stream_id=7)
+    assert ((E2h.float().sum(0) / 4096.0 - E).abs() <= 2.0 ** -21 * E.abs() + 1e-12).all()
+    for n, nb, spread in ((128, 256, 0), (384, 256, 3), (1024, 512, 6), (512, 384, 2), (2048, 4096, 4)):
+        Lh = np.tril(rng.standard_normal((n, n))) * 10 ** rng.uniform(-spread, 0, (n, n)) * 3.0
+        L = torch.tensor(Lh, dtype=torch.float32, device=DEV) + torch.triu(torch.full((n, n), 5.0, device=DEV), 1)
+        L2, inv = ops.split_h2(L, torch.tril(L).abs().max(), lower=True)
+        E2h = ops.randn_h2((nb, n), DEV, seed=3, stream_id=n)
+        E = ops.randn((nb, n), torch.float32, DEV, seed=3, stream_id=n)
+        E2 = ops.randn((nb, n), torch.float32, DEV, seed=4, stream_id=n)
+        Fo = E.double() @ torch.tril(L).double().T
+        F, Y = ops.draw_h2(L2, inv, E2h, E2, 0.3, want_f=True)
+        Ff = ops.draw(L, E)                                            # f32 MFMA
+        Fb = ops.draw_b3(ops.split_b3(L, lower=True), ops.randn_b3((nb, n), DEV, seed=3, stream_id=n))
+        e_h2, e_f32, e_b3 = rel(F, Fo.cpu().numpy()), rel(Ff, Fo.cpu().numpy()), rel(Fb, Fo.cpu().numpy())
+        assert e_h2 < 1e-5 and e_h2 < 3 * e_f32 + 2e-7, (n, nb, e_h2, e_f32, e_b3)
+        assert rel(Y, (Fo + 0.3 * E2.double()).cpu().numpy()) < 1e-5
+        print("h2 draw n=%d nb=%d: rel err fp16x2 %.2e  f32 MFMA %.2e  bf16x3 %.2e" % (n, nb, e_h2, e_f32, e_b3))

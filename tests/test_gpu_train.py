@@ -53,8 +53,8 @@ def test_step_engine_matches_oracle_train_steps(tdt, ndt, tol):
 
 
 def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
-    """Shapes that put the engine's factorisations and draws on the bf16 matrix pipe (float32, n % 256 == 0, B % 256 == 0):
-    same float32 bar against oracle.train_step as the f32-MFMA engine, and the two engines agree."""
+    """Shapes that put the engine's factorisations and draws on the bf16 matrix pipe (float32, n % 256 == 0, B % 256 == 0),
+    and the opt-in fp16 x 2 draw: same float32 bar against oracle.train_step as the f32-MFMA engine, and the engines agree."""
     from gp_vae_amd import ops, parallel
     from gp_vae_amd.gp import draw_hyper
     from gp_vae_amd.vae import StepEngine, SVIState
@@ -64,9 +64,9 @@ def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
     x = np.stack([u.ravel(), v.ravel()], 1)
     keys = [(5, i) for i in range(3)]
     res = {}
-    for mode in ("bf16x3", "f32"):
+    for mode in ("bf16x3", "f16x2", "f32"):
         eng = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=torch.float32, seed=1, group=2, mfma=mode)
-        assert eng.b3 == (mode == "bf16x3")
+        assert eng.b3 == (mode == "bf16x3") and eng.h2 == (mode == "f16x2")
         p0 = {k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}
         st = SVIState(torch.tensor(orc.flatten(p0), dtype=torch.float32, device=DEV))
         res[mode] = (eng.run(keys, st, train=True).item(), st.params.cpu().numpy())
@@ -79,10 +79,12 @@ def test_step_engine_bf16x3_draws_match_oracle_and_f32_engine():
                      for i, s in ((1, (B, n)), (2, (B, n)), (3, (B, dims[2]))))
         loss, p, m, vv = orc.train_step(p, m, vv, t, x, draw_hyper(parallel.step_rng(1, 0, key)), E, E2, ez, lr, jit)
         want += loss
-    for mode in ("bf16x3", "f32"):
+    for mode in ("bf16x3", "f16x2", "f32"):
         assert abs(res[mode][0] - want) < 2e-3 * abs(want), mode
         assert rel(res[mode][1], orc.flatten(p)) < 2e-3, mode
     assert abs(res["bf16x3"][0] - res["f32"][0]) < 1e-4 * abs(want)
+    # fp16 x 2 rounds the draw's operands to 22 bits: the same bar against the f32 engine as bf16 x 3
+    assert abs(res["f16x2"][0] - res["f32"][0]) < 1e-4 * abs(want)
     with pytest.raises(Exception):
         StepEngine(torch.tensor(np.arange(300) / 300), jit, dims, 100, lr, mfma="bf16x3")
 
@@ -95,7 +97,7 @@ def test_training_run_is_bitwise_reproducible():
     g = np.arange(0, 1, 1 / 32)
     u, v = np.meshgrid(g, g)
     x2 = np.stack([u.ravel(), v.ravel()], 1)
-    cases = [(x2, 256, (20, 12, 5), "bf16x3"), (x2, 256, (20, 12, 5), "f32"), (np.arange(300) / 300, 100, (35, 30, 10), "auto")]
+    cases = [(x2, 256, (20, 12, 5), "bf16x3"), (x2, 256, (20, 12, 5), "f16x2"), (x2, 256, (20, 12, 5), "f32"), (np.arange(300) / 300, 100, (35, 30, 10), "auto")]
     for x, B, dims, mode in cases:
         outs = []
         for rep in range(2):

@@ -15,14 +15,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ __bf16 to_bf16(float x) { return (__bf16)x; }  // round to nearest even
 
 // accuracy: one wave per block computes a 32 x 32 tile of C = A Bt^T, A, Bt: [32 x K] row-major
-__global__ void acc_kernel(int K, const float *A, const float *Bt, float *Cf32, float *Cb3) {
+__global__ void acc_kernel(int K, const float *A, const float *Bt, float *Cf32, float *Cb3, float *Ch2 = nullptr) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  f32x16 c32, c3;
-  for (int i = 0; i < 16; ++i) c32[i] = c3[i] = 0.f;
+  f32x16 c32, c3, ch;
+  for (int i = 0; i < 16; ++i) c32[i] = c3[i] = ch[i] = 0.f;
   for (int k = 0; k < K; k += 2) c32 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * K + k + h], Bt[r * K + k + h], c32, 0, 0, 0);
   for (int k = 0; k < K; k += 16) {
     bf16x8 a[3], b[3];
@@ -41,10 +42,23 @@ __global__ void acc_kernel(int K, const float *A, const float *Bt, float *Cf32, 
     c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c3, 0, 0, 0);
     c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c3, 0, 0, 0);
   }
+  // two fp16 pieces per operand (11 + 11 significand bits), three products: a0 b0 + a0 b1 + a1 b0
+  for (int k = 0; k < K; k += 16) {
+    f16x8 a[2], b[2];
+    for (int j = 0; j < 8; ++j) {
+      float x = A[r * K + k + 8 * h + j], y = Bt[r * K + k + 8 * h + j];
+      a[0][j] = (_Float16)x; a[1][j] = (_Float16)(x - (float)a[0][j]);
+      b[0][j] = (_Float16)y; b[1][j] = (_Float16)(y - (float)b[0][j]);
+    }
+    ch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], ch, 0, 0, 0);
+    ch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], ch, 0, 0, 0);
+    ch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], ch, 0, 0, 0);
+  }
   for (int i = 0; i < 16; ++i) {
     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
     Cf32[row * 32 + r] = c32[i];
     Cb3[row * 32 + r] = c3[i];
+    if (Ch2) Ch2[row * 32 + r] = ch[i];
   }
 }
 
@@ -82,24 +96,26 @@ int main() {
   auto rnd = []() { return (float)rand() / RAND_MAX * 2.f - 1.f; };
   // a Cholesky-like worst case as well: rows nearly parallel (long-lengthscale Gram factors)
   for (int i = 0; i < 32 * K; ++i) { A[i] = 1.0f + 1e-3f * rnd(); Bt[i] = rnd(); }
-  float *dA, *dB, *dC1, *dC2;
-  hipMalloc(&dA, 32 * K * 4); hipMalloc(&dB, 32 * K * 4); hipMalloc(&dC1, 4096); hipMalloc(&dC2, 4096);
+  float *dA, *dB, *dC1, *dC2, *dC3;
+  hipMalloc(&dA, 32 * K * 4); hipMalloc(&dB, 32 * K * 4); hipMalloc(&dC1, 4096); hipMalloc(&dC2, 4096); hipMalloc(&dC3, 4096);
   hipMemcpy(dA, A.data(), 32 * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(dB, Bt.data(), 32 * K * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(acc_kernel, dim3(1), dim3(64), 0, 0, K, dA, dB, dC1, dC2);
-  std::vector<float> C1(1024), C2(1024);
+  hipLaunchKernelGGL(acc_kernel, dim3(1), dim3(64), 0, 0, K, dA, dB, dC1, dC2, dC3);
+  std::vector<float> C1(1024), C2(1024), C3(1024);
   hipMemcpy(C1.data(), dC1, 4096, hipMemcpyDeviceToHost);
   hipMemcpy(C2.data(), dC2, 4096, hipMemcpyDeviceToHost);
-  double e1 = 0, e2 = 0, nrm = 0;
+  hipMemcpy(C3.data(), dC3, 4096, hipMemcpyDeviceToHost);
+  double e1 = 0, e2 = 0, e3 = 0, nrm = 0;
   for (int i = 0; i < 32; ++i)
     for (int j = 0; j < 32; ++j) {
       double ref = 0, mag = 0;
       for (int k = 0; k < K; ++k) { ref += (double)A[i * K + k] * Bt[j * K + k]; mag += fabs((double)A[i * K + k] * Bt[j * K + k]); }
       e1 = fmax(e1, fabs(C1[i * 32 + j] - ref) / mag);
       e2 = fmax(e2, fabs(C2[i * 32 + j] - ref) / mag);
+      e3 = fmax(e3, fabs(C3[i * 32 + j] - ref) / mag);
       nrm = fmax(nrm, mag);
     }
-  printf("K = %d: max |err| / sum|a b|   f32 MFMA %.3e   bf16 x 3 (6 products) %.3e   (f32 eps = 6e-8)\n", K, e1, e2);
+  printf("K = %d: max |err| / sum|a b|   f32 MFMA %.3e   bf16 x 3 (6 products) %.3e   fp16 x 2 (3 products, operands in [-1, 1]) %.3e   (f32 eps = 6e-8)\n", K, e1, e2, e3);
 
   float *sink; hipMalloc(&sink, 4);
   const int iters = 2000, blocks = 1024;
