@@ -37,6 +37,8 @@ SIGNATURES = {
     "gpvae_potrf_b3_supported": (_i, [_i64]),
     "gpvae_potrf_b3_workspace_bytes": (_i64, [_i64, _i]),
     "gpvae_potrf_b3": (_i, [_vp, _i64, _i, _vp, _i64, _i64, _vp, _i, _vp, _vp, _i64, _i64, _i64]),
+    "gpvae_potrf_h2_workspace_bytes": (_i64, [_i64, _i]),
+    "gpvae_potrf_h2": (_i, [_vp, _i64, _i, _vp, _i64, _i64, _vp, _i, _vp, _vp, _i64, _i64, _i64, _vp]),
     "gpvae_split_b3": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i64, _i, _vp, _i64, _i64, _i64]),
     "gpvae_randn_b3": (_i, [_vp, _i64, _u64, _u64, _vp, _i64]),
     "gpvae_draw_b3_supported": (_i, [_i64, _i64]),

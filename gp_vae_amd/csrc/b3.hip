@@ -65,21 +65,8 @@ __global__ __launch_bounds__(256) void randn_b3_kernel(int64_t count, uint64_t s
 }
 
 // ---- fp16 x 2: two fp16 planes of a SCALED operand (b3.hpp, NP = 2) -----------------------------------------
-// x * 2^e = h + l + (error <= 2^-22 |x| 2^e): h = fp16(x 2^e), l = fp16(x 2^e - h).  e is chosen per matrix from
-// a caller-given bound on |x| so that bound * 2^e lies in (2^13, 2^14] (fp16 overflows at 2^16); entries below
-// 2^-17 of the bound keep fewer bits in l (fp16 subnormals), an absolute error of 2^-39 of the bound.
+// split2_f16 / h2_scale: b3.hpp
 constexpr float H2_E_SCALE = 4096.0f;  // standard normals: |e| < 7.2 from 32-bit uniforms, 7.2 * 2^12 < 2^15
-
-__device__ __forceinline__ void split2_f16(float v, _Float16 &h, _Float16 &l) {
-  asm volatile("" : "+v"(v));  // as in split3_bf16: v must be the rounded float
-  h = (_Float16)v;
-  l = (_Float16)(v - (float)h);
-}
-__device__ __forceinline__ float h2_scale(float bound) {  // 2^e with bound * 2^e in (2^13, 2^14]
-  int ex;
-  (void)frexpf(bound, &ex);  // bound = m 2^ex, m in [0.5, 1)
-  return ldexpf(1.0f, 14 - ex);
-}
 
 // grid (ceil(cols/1024), rows, batch); 4 elements per thread
 __global__ __launch_bounds__(256) void split_h2_kernel(int64_t rows, int64_t cols, const float *X, int64_t ldx,

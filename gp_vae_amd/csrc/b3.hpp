@@ -44,6 +44,20 @@ __device__ __forceinline__ void split3_bf16(float v, __bf16 &h, __bf16 &m, __bf1
   l = (__bf16)(r1 - (float)m);
 }
 
+// fp16 x 2: x * 2^e = h + l + (error <= 2^-22 |x| 2^e): h = fp16(x 2^e), l = fp16(x 2^e - h).  e is chosen per
+// matrix from a bound on |x| so that bound * 2^e lies in (2^13, 2^14] (fp16 overflows at 2^16); entries below
+// 2^-17 of the bound keep fewer bits in l (fp16 subnormals), an absolute error of 2^-39 of the bound.
+__device__ __forceinline__ void split2_f16(float v, _Float16 &h, _Float16 &l) {
+  asm volatile("" : "+v"(v));  // as in split3_bf16: v must be the rounded float
+  h = (_Float16)v;
+  l = (_Float16)(v - (float)h);
+}
+__device__ __forceinline__ float h2_scale(float bound) {  // 2^e with bound * 2^e in (2^13, 2^14]
+  int ex;
+  (void)frexpf(bound, &ex);  // bound = m 2^ex, m in [0.5, 1)
+  return ldexpf(1.0f, 14 - ex);
+}
+
 // WFM_ = 4: the 256 x 128 tile described above.  WFM_ = 2: a 128 x 128 tile (wave tiles 64 x 64, 99.8 KB of
 // LDS) for problems with fewer 256-row tiles than CUs — half the MFMAs per k-tile against two thirds of the
 // operand bytes, but twice the workgroups.

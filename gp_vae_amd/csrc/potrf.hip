@@ -55,10 +55,14 @@ template <typename T> struct VRows {
 //   workspace mode (gpvae_potrf): only the current outer panel, [row][256], coloff = cJ, rows below
 //     the outer block only (first_row = cJ + 256);
 //   factor mode (gpvae_potrf_b3): the caller's whole L3 [n][ld3], coloff = 0, every row.
+// np = 2 (gpvae_potrf_h2): two fp16 planes of the factor TIMES scale[b] (a power of two chosen from the largest
+// diagonal entry of matrix b: |L_ij| <= sqrt(max K_ii)), same addressing (two-byte elements either way).
 struct B3Out {
   __bf16 *p;
   int64_t ld, plane, stride;
-  int whole;  // factor mode
+  int whole;           // factor mode
+  int np;              // planes per operand: 3 (bf16) or 2 (fp16)
+  const float *scale;  // np == 2: per matrix
 };
 
 template <typename T> struct PanelCfg;
@@ -469,13 +473,22 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
       // rows below the outer block also go out as three bf16 planes [plane][row][256]: the operand of
       // the bf16 x 3 trailing update (potrf_syrk_b3_kernel), pieces summing to the float exactly
       if (o3.p != nullptr && (o3.whole || rbase + s >= cJ + NBO)) {
-        __bf16 hh[4], mm[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split3_bf16(tp[e], hh[e], mm[e], ll[e]);
         __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (o3.whole ? c0 : c0 - cJ) + j;
-        *reinterpret_cast<uint64_t *>(q) = *reinterpret_cast<const uint64_t *>(hh);
-        *reinterpret_cast<uint64_t *>(q + o3.plane) = *reinterpret_cast<const uint64_t *>(mm);
-        *reinterpret_cast<uint64_t *>(q + 2 * o3.plane) = *reinterpret_cast<const uint64_t *>(ll);
+        if (o3.np == 2) {
+          const float sc = o3.scale[b];
+          _Float16 hh[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16(tp[e] * sc, hh[e], ll[e]);
+          *reinterpret_cast<uint64_t *>(q) = *reinterpret_cast<const uint64_t *>(hh);
+          *reinterpret_cast<uint64_t *>(q + o3.plane) = *reinterpret_cast<const uint64_t *>(ll);
+        } else {
+          __bf16 hh[4], mm[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split3_bf16(tp[e], hh[e], mm[e], ll[e]);
+          *reinterpret_cast<uint64_t *>(q) = *reinterpret_cast<const uint64_t *>(hh);
+          *reinterpret_cast<uint64_t *>(q + o3.plane) = *reinterpret_cast<const uint64_t *>(mm);
+          *reinterpret_cast<uint64_t *>(q + 2 * o3.plane) = *reinterpret_cast<const uint64_t *>(ll);
+        }
       }
     }
     if (vcols) {
@@ -660,11 +673,15 @@ struct SyrkB3Map {
   }
 };
 
+// NP = 2: the planes hold L * s (fp16 x 2, b3.hpp); the accumulators start from -C s^2 and are multiplied by
+// 1 / s^2 before the store (powers of two: exact).
+template <int NP>
 __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
                                                                     int64_t strideA, B3Out o3,
                                                                     int64_t cJ, int64_t kend,
                                                                     SyrkB3Map map) {
   using M = Mfma<float>;
+  using PipeB3 = PipeB3T<4, NP>;
   __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
   int b, tr, tc;
   if (!map.decode(blockIdx.x, b, tr, tc)) return;
@@ -692,7 +709,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
     for (int fn = 0; fn < PipeB3::WFN; ++fn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] = -P.acc[fm][fn][r];
+  if constexpr (NP == 2) {
+    const float sc = o3.scale[b], s2 = sc * sc;
+#pragma unroll
+    for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] *= s2;
+  }
   P.run(lds, 0, NBO);
+  if constexpr (NP == 2) {
+    const float is = 1.0f / o3.scale[b], is2 = is * is;
+#pragma unroll
+    for (int fm = 0; fm < PipeB3::WFM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < PipeB3::WFN; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] *= is2;
+  }
   if (tc < 2 * tr) {  // wholly below the diagonal
 #pragma unroll
     for (int fm = 0; fm < PipeB3::WFM; ++fm)
@@ -743,6 +778,21 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
     if (o3.p != nullptr && o3.whole && in_diag) {
       __bf16 *q = o3.p + (int64_t)b * o3.stride;
       const bool even = (blockIdx.y & 1) == 0 && j + NB < n;
+      if (o3.np == 2) {
+        _Float16 *q2 = reinterpret_cast<_Float16 *>(q);
+        const float sc = o3.scale[b];
+        for (int64_t i = i0 + ry; i < i1; i += rs) {
+          _Float16 hh, ll;
+          split2_f16(failed ? dnan<float>() : l11[(i - i0) * NB + (j - i0)] * sc, hh, ll);
+          q2[i * o3.ld + j] = hh;
+          q2[o3.plane + i * o3.ld + j] = ll;
+          if (even) {
+            q2[i * o3.ld + j + NB] = (_Float16)0.f;
+            q2[o3.plane + i * o3.ld + j + NB] = (_Float16)0.f;
+          }
+        }
+        return;
+      }
       for (int64_t i = i0 + ry; i < i1; i += rs) {
         __bf16 hh, mm, ll;
         split3_bf16(failed ? dnan<float>() : l11[(i - i0) * NB + (j - i0)], hh, mm, ll);
@@ -759,6 +809,35 @@ __global__ void potrf_finalize_kernel(T *A, int64_t lda, int64_t strideA, int64_
   }
 }
 
+// fp16 x 2 factor: scale[b] = 2^e with sqrt(max_i K_ii) 2^e in (2^13, 2^14] — every |L_ij| <= sqrt(K_ii) — and its
+// inverse for the consumer of the planes.  A matrix without a positive finite diagonal gets scale 1 (it fails).
+__global__ __launch_bounds__(256) void potrf_h2_scale_kernel(const float *A, int64_t lda, int64_t strideA, int64_t n,
+                                                             float *scale, float *inv_scale) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const float *Ab = A + (int64_t)b * strideA;
+  float m = 0.f;
+  bool bad = false;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float d = Ab[i * lda + i];
+    bad = bad || !(d == d) || d > 3.0e38f;
+    m = fmaxf(m, d);
+  }
+  red[threadIdx.x] = bad ? -1.f : m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = 0.f;
+    bool any_bad = false;
+    for (int t = 0; t < 256; ++t) {
+      any_bad = any_bad || red[t] < 0.f;
+      mm = fmaxf(mm, red[t]);
+    }
+    const float sc = (any_bad || !(mm > 0.f)) ? 1.0f : h2_scale(sqrtf(mm));
+    scale[b] = sc;
+    inv_scale[b] = 1.0f / sc;
+  }
+}
+
 // workspace: [parked diagonal blocks | bf16 planes of the current outer panel (b3 path only)]
 static inline int64_t l11_bytes(int64_t es, int64_t n, int batch) {
   return round_up((int64_t)batch * round_up(n, NB) * NB * es, 256);
@@ -770,7 +849,7 @@ static inline bool potrf_b3_ok(bool f32, int64_t n, int64_t mx) {
 template <typename T, bool VECM>
 static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
-                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0}) {
+                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0, 3, nullptr}) {
   constexpr int NCH = PanelCfg<T>::NCH;
   VRows<T> vr{(T *)A, lda, n, (T *)X, ldx, round_up(n, NB), mx};
   const int64_t Mv = vr.npad + mx;
@@ -780,7 +859,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
   B3Out o3{nullptr, 0, 0, 0, 0};
   if (b3) {
     if (ext.p != nullptr) o3 = ext;  // the caller's whole-factor planes double as the panel operand
-    else o3 = B3Out{(__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)), NBO, vr.npad * NBO, 3 * vr.npad * NBO, 0};
+    else o3 = B3Out{(__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)), NBO, vr.npad * NBO, 3 * vr.npad * NBO, 0, 3, nullptr};
   } else if (ext.p != nullptr) {
     set_error("gpvae_potrf_b3: needs 16-byte aligned rows (lda %% 4 == 0) and 128*lda*4 < 2^31");
     return -5;
@@ -802,8 +881,12 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
       if (b3 && kend < n) {
         const int R = (int)((n - kend) / B3_TM);
         const SyrkB3Map map{R, batch, (int64_t)R * (R + 1)};
-        hipLaunchKernelGGL(potrf_syrk_b3_kernel, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                           lda, strideA, o3, cJ, kend, map);
+        if (o3.np == 2)
+          hipLaunchKernelGGL(potrf_syrk_b3_kernel<2>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
+                             lda, strideA, o3, cJ, kend, map);
+        else
+          hipLaunchKernelGGL(potrf_syrk_b3_kernel<3>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
+                             lda, strideA, o3, cJ, kend, map);
         continue;
       }
     }
@@ -826,7 +909,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
 template <typename T>
 static int run_potrf(hipStream_t st, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
                      int64_t mx, void *X, int64_t ldx, int64_t strideX, int32_t *info, int flags,
-                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0}) {
+                     void *work, B3Out ext = B3Out{nullptr, 0, 0, 0, 0, 3, nullptr}) {
   constexpr int VEC = VecT<T>::N;
   const bool vec = kc_vec_ok<T>(A, lda) && (strideA % VEC == 0) &&
                    (mx == 0 || (kc_vec_ok<T>(X, ldx) && (strideX % VEC == 0)));
@@ -923,5 +1006,42 @@ extern "C" int gpvae_potrf_b3(void *stream, int64_t n, int batch, void *A, int64
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 3, "gpvae_potrf_b3: batch x tiles exceeds one launch; split the batch");
   }
   return run_potrf<float>((hipStream_t)stream, n, batch, A, lda, strideA, 0, nullptr, 0, 0, info, flags, work,
-                          B3Out{(__bf16 *)L3, ld3, plane, stride3, 1});
+                          B3Out{(__bf16 *)L3, ld3, plane, stride3, 1, 3, nullptr});
+}
+
+// The same with the factor left as fp16 x 2 planes of L * scale[b] (the operand gpvae_draw_h2 wants) and the
+// trailing updates on those planes: half the matrix work of bf16 x 3, operands rounded to 22 bits.
+extern "C" int64_t gpvae_potrf_h2_workspace_bytes(int64_t n, int batch) {
+  if (n <= 0 || batch <= 0) return 0;
+  return l11_bytes(4, n, batch) + round_up((int64_t)batch * 4, 256);
+}
+
+extern "C" int gpvae_potrf_h2(void *stream, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                              int32_t *info, int flags, void *work, void *L2, int64_t ld2,
+                              int64_t plane, int64_t stride2, float *inv_scale) {
+  GPVAE_REQUIRE(n >= 0, 2, "gpvae_potrf_h2: n < 0");
+  GPVAE_REQUIRE(batch >= 0 && batch <= 65535, 3, "gpvae_potrf_h2: batch out of range [0,65535]");
+  if (n == 0 || batch == 0) return 0;
+  GPVAE_REQUIRE(potrf_b3_ok(true, n, 0), 2, "gpvae_potrf_h2: n must be a multiple of 256 and >= 512 (gpvae_potrf_b3_supported)");
+  GPVAE_REQUIRE(A && aligned16(A), 4, "gpvae_potrf_h2: A is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(lda >= n && lda % 4 == 0, 5, "gpvae_potrf_h2: lda < n or not a multiple of 4");
+  GPVAE_REQUIRE(batch == 1 || (strideA >= n * lda && strideA % 4 == 0), 6, "gpvae_potrf_h2: strideA < n*lda or not a multiple of 4");
+  GPVAE_REQUIRE(info, 7, "gpvae_potrf_h2: info is NULL");
+  GPVAE_REQUIRE(work && aligned16(work), 9, "gpvae_potrf_h2: work is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(L2 && aligned16(L2), 10, "gpvae_potrf_h2: L2 is NULL or not 16-byte aligned");
+  GPVAE_REQUIRE(ld2 >= n && ld2 % 8 == 0, 11, "gpvae_potrf_h2: ld2 < n or not a multiple of 8");
+  GPVAE_REQUIRE(plane >= n * ld2 && plane % 8 == 0, 12, "gpvae_potrf_h2: plane < n*ld2 or not a multiple of 8");
+  GPVAE_REQUIRE(batch == 1 || (stride2 >= 2 * plane && stride2 % 8 == 0), 13, "gpvae_potrf_h2: stride2 < 2*plane or not a multiple of 8");
+  GPVAE_REQUIRE(inv_scale, 14, "gpvae_potrf_h2: inv_scale is NULL");
+  GPVAE_REQUIRE((PipeB3T<4, 2>::usable(ld2, ld2)), 11, "gpvae_potrf_h2: ld2 too large");
+  {
+    const int rt = (int)cdiv(round_up(n, NB), SBM), ct = (int)cdiv(n, SBM);
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 3, "gpvae_potrf_h2: batch x tiles exceeds one launch; split the batch");
+  }
+  float *scale = (float *)((char *)work + l11_bytes(4, n, batch));
+  hipLaunchKernelGGL(potrf_h2_scale_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const float *)A,
+                     lda, strideA, n, scale, inv_scale);
+  return run_potrf<float>((hipStream_t)stream, n, batch, A, lda, strideA, 0, nullptr, 0, 0, info, flags, work,
+                          B3Out{(__bf16 *)L2, ld2, plane, stride2, 1, 2, scale});
 }

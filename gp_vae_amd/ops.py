@@ -351,6 +351,30 @@ def potrf_b3_(A, L3=None, zero_upper=False, nan_on_fail=False, work=None, info=N
     return info, (o if A.dim() == 3 else o[0])
 
 
+def potrf_h2_(A, L2=None, inv_scale=None, zero_upper=False, nan_on_fail=False, work=None, info=None):
+    """potrf_b3_ with the factor left as fp16 x 2 planes L2 [batch,2,n,n] of L * 2^e_b for draw_h2 and the trailing
+    updates on those planes; inv_scale [batch] float32 = 2^-e_b.  Returns (info, L2, inv_scale)."""
+    _dev(A, L2, inv_scale)
+    A3 = A if A.dim() == 3 else A.unsqueeze(0)
+    batch, n = A3.shape[0], A3.shape[1]
+    if A3.dtype != torch.float32 or A3.shape[2] != n or A3.stride(2) != 1:
+        raise GpvaeError("potrf_h2_: A must be float32 [batch,n,n] with unit column stride")
+    if L2 is None:
+        L2 = torch.empty((batch, 2, n, n), dtype=torch.float16, device=A.device)
+    if inv_scale is None:
+        inv_scale = torch.empty((batch,), dtype=torch.float32, device=A.device)
+    o = L2.view(batch, 2, n, n)
+    if info is None:
+        info = torch.empty((batch,), dtype=torch.int32, device=A.device)
+    lib = _lib.load()
+    if work is None:
+        work = torch.empty(max(16, lib.gpvae_potrf_h2_workspace_bytes(n, batch)), dtype=torch.uint8, device=A.device)
+    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    check(lib.gpvae_potrf_h2(_stream(), n, batch, _p(A3), A3.stride(1), A3.stride(0), _p(info), flags, _p(work),
+                             _p(o), o.stride(2), o.stride(1), o.stride(0), _p(inv_scale)), "gpvae_potrf_h2")
+    return info, (o if A.dim() == 3 else o[0]), inv_scale
+
+
 def randn_b3(shape, device="cuda", seed=0, stream_id=0, out=None):
     """The float32 normals of randn(shape, seed, stream_id) as bf16 planes [3, *shape]."""
     if out is None:

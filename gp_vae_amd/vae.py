@@ -306,8 +306,8 @@ class StepEngine():
         # MFMA rate, csrc/b3.hpp): E is generated straight as bf16 planes, L is split on the factor stream.
         # mfma="f16x2" (opt-in): the draw on two fp16 planes per operand — half the matrix work of bf16 x 3; the
         # operands are rounded to 22 bits, measured errors are those of the f32-MFMA kernel or below
-        # (include/gpvae.h, tests/test_gpu_seams.py::test_h2_planes_and_draw).  The factor comes from plain
-        # gpvae_potrf and is split on the factor stream.
+        # (include/gpvae.h, tests/test_gpu_seams.py::test_h2_planes_and_draw).  gpvae_potrf_h2 leaves the factor
+        # as such planes and runs its trailing updates on them.
         if mfma not in ("auto", "f32", "bf16x3", "f16x2"):
             raise ValueError("mfma must be 'auto', 'f32', 'bf16x3' or 'f16x2'")
         self.b3 = (mfma != "f32" and dtype == torch.float32 and self.ld == n and ops.draw_b3_supported(n, B)
@@ -320,7 +320,6 @@ class StepEngine():
             self.Eh = torch.empty((2, B, n), dtype=torch.float16, device=dev)
             self.L2buf = [torch.empty((G, 2, n, n), dtype=torch.float16, device=dev) for _ in range(2)]
             self.L2inv = [torch.empty(G, dtype=torch.float32, device=dev) for _ in range(2)]
-            self.L2bound = [torch.empty(G, dtype=torch.float32, device=dev) for _ in range(2)]
         if self.b3:
             self.E3 = torch.empty((3, B, n), dtype=torch.bfloat16, device=dev)
             self.L3buf = [torch.empty((G, 3, n, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]
@@ -413,16 +412,14 @@ class StepEngine():
                 check(lib.gpvae_potrf_b3(_stream(), self.n, g, _p(K), self.ld, self.n * self.ld, _p(self.info[slot]),
                                          0, _p(self.pwork[slot]), _p(self.L3buf[slot]), self.n, self.n * self.n,
                                          3 * self.n * self.n), "gpvae_potrf_b3")
+            elif self.h2:  # the same with fp16 x 2 planes of L * 2^e, e from the largest diagonal entry
+                check(lib.gpvae_potrf_h2(_stream(), self.n, g, _p(K), self.ld, self.n * self.ld, _p(self.info[slot]),
+                                         0, _p(self.pwork[slot]), _p(self.L2buf[slot]), self.n, self.n * self.n,
+                                         2 * self.n * self.n, _p(self.L2inv[slot])), "gpvae_potrf_h2")
             else:
                 check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
                                       0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
                       "gpvae_potrf")
-            if self.h2:
-                # |L_ij| <= sqrt(K_ii) = sqrt(var + jitter): the bound the fp16 scaling is chosen from
-                torch.sqrt(hd[0] + float(self.jitter), out=self.L2bound[slot])
-                check(lib.gpvae_split_h2(_stream(), self.n, self.n, g, _p(K), self.ld, self.n * self.ld, 1,
-                                         _p(self.L2bound[slot]), _p(self.L2buf[slot]), self.n, self.n * self.n,
-                                         2 * self.n * self.n, _p(self.L2inv[slot])), "gpvae_split_h2")
             self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
             self.ev_ready[slot].record(stream)
 

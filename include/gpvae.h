@@ -172,7 +172,19 @@ int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3, int64_t l
  *   gpvae_randn_h2   the normals of gpvae_randn(GPVAE_F32, count, seed, stream_id), times 2^12, as two planes.
  *   gpvae_draw_h2    F = E L^T, Y = F + sigma*E2 from such planes (shapes as gpvae_draw_b3_supported); the
  *                    accumulators are rescaled by inv_scale_L[0] * 2^-12 (exact).  Bound: fp16 MFMA
- *                    (3 n^2 nb flop issued).                                                              */
+ *                    (3 n^2 nb flop issued).
+ *   gpvae_potrf_h2   gpvae_potrf_b3 with the factor left as fp16 x 2 planes L2 [batch][2][n, ld2] of L * 2^e_b
+ *                    (zeros wherever gpvae_draw_h2 reads above the diagonal) and the trailing updates on those
+ *                    planes.  e_b comes from the largest diagonal entry of matrix b (|L_ij| <= sqrt(K_ii));
+ *                    inv_scale[b] = 2^-e_b (device, f32) is written for the draw.  Shapes, A, info, flags as
+ *                    gpvae_potrf_b3; work: gpvae_potrf_h2_workspace_bytes().  The update C - P P^T then carries
+ *                    the operands' 2^-22 rounding: backward error max|L L^T - K| / max K_ii stays at the
+ *                    float32 level (<= 2.5e-7 measured, tests) but can be up to 4x LAPACK spotrf's on
+ *                    near-singular K.                                                                      */
+int64_t gpvae_potrf_h2_workspace_bytes(int64_t n, int batch);
+int gpvae_potrf_h2(void *stream, int64_t n, int batch, void *A, int64_t lda, int64_t strideA,
+                   int32_t *info, int flags, void *work, void *L2, int64_t ld2, int64_t plane,
+                   int64_t stride2, float *inv_scale);
 int gpvae_split_h2(void *stream, int64_t rows, int64_t cols, int batch, const void *X, int64_t ldx,
                    int64_t strideX, int lower, const void *bound, void *out2, int64_t ld2, int64_t plane,
                    int64_t stride2, void *inv_scale);

@@ -3,6 +3,7 @@ Predictive(gp.sample) with per-sample hyper-parameters (batched factors + gpvae_
 vae_encoder's apply (gpvae_encoder_fwd), SVI.init/update/evaluate/get_params driven by an EXTERNAL
 batch, the literal training loop vs the pipelined StepEngine, regression / gp_regression handed to the
 MCMC drivers, chain sharding.  Everything goes ctypes -> C ABI; the checker is the oracle."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -551,3 +552,43 @@ def test_h2_planes_and_draw():
         assert e_h2 < 1e-5 and e_h2 < 3 * e_f32 + 2e-7, (n, nb, e_h2, e_f32, e_b3)
         assert rel(Y, (Fo + 0.3 * E2.double()).cpu().numpy()) < 1e-5
         print("h2 draw n=%d nb=%d: rel err fp16x2 %.2e  f32 MFMA %.2e  bf16x3 %.2e" % (n, nb, e_h2, e_f32, e_b3))
+
+
+def test_potrf_h2_factor_and_planes():
+    """gpvae_potrf_h2: the float32 factor it leaves has a float32-level backward error (within 4x of gpvae_potrf's
+    on the same matrix, near-singular K = var 11^T + jitter I included), its planes are the factor times 2^e to
+    2^-22 with zeros wherever the draw reads above the diagonal, and draws from them meet the draw's float32 bar.
+    Non-PD matrix in the batch: same info as gpvae_potrf."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(6)
+    for n, batch in ((512, 3), (1280, 9), (2048, 3)):
+        x = torch.tensor(rng.random((n, 2)), dtype=torch.float32, device=DEV)
+        ls = torch.linspace(0.05, 0.6, batch, device=DEV)
+        var = torch.tensor(10 ** rng.uniform(-2, 2, batch), dtype=torch.float32, device=DEV)
+        K = ops.gram_se(x, x, var, ls, 1e-3).reshape(batch, n, n)
+        K[batch - 1] = var[batch - 1] * (1.0 + 1e-4 * torch.eye(n, device=DEV))  # near rank one: ls -> infinity
+        K[1, 300, 300] = -1.0  # not positive definite from column 301
+        A = K.clone()
+        junk = torch.full((batch, 2, n, n), 7.0, dtype=torch.float16, device=DEV)
+        info, L2, inv = ops.potrf_h2_(A, junk)
+        assert info.cpu().tolist() == [0, 301] + [0] * (batch - 2)
+        ref = K.clone()
+        assert torch.equal(ops.potrf_(ref, zero_upper=False, nan_on_fail=False), info)
+        for b in (0, 2, batch - 1):
+            L, Lr, Kb = torch.tril(A[b]).double(), torch.tril(ref[b]).double(), K[b].double()
+            top = Kb.diagonal().max().item()
+            e_h2, e_ref = ((L @ L.T - Kb).abs().max() / top).item(), ((Lr @ Lr.T - Kb).abs().max() / top).item()
+            print("potrf_h2 n=%d b=%d: max|LL^T - K| / max K_ii  fp16x2 %.2e  gpvae_potrf %.2e" % (n, b, e_h2, e_ref))
+            assert e_h2 < 2e-6 and e_h2 < 4 * e_ref + 5e-8, (n, b, e_h2, e_ref)
+            s = 1.0 / inv[b].item()
+            assert 2.0 ** 13 < math.sqrt(top) * s <= 2.0 ** 14 * (1 + 1e-6)
+            back = L2[b].float().sum(0).double() / s
+            lim = 2.0 ** -21 * L.abs() + 2.0 ** -37 * math.sqrt(top)
+            assert ((torch.tril(back) - L).abs() <= lim).all()
+            E2h = ops.randn_h2((256, n), DEV, seed=b, stream_id=2)
+            want = ops.draw_h2(*ops.split_h2(A[b], math.sqrt(top), lower=True), E2h)
+            assert torch.equal(ops.draw_h2(L2[b], inv[b:b + 1], E2h), want)
+        A2 = K.clone()
+        info2, L22, inv2 = ops.potrf_h2_(A2, nan_on_fail=True)
+        assert torch.isnan(ops.draw_h2(L22[1], inv2[1:2], ops.randn_h2((256, n), DEV, seed=1))).all()
+        assert not torch.isnan(ops.draw_h2(L22[0], inv2[0:1], ops.randn_h2((256, n), DEV, seed=1))).any()
