@@ -102,6 +102,17 @@ def test_argument_validation_of_the_round_2_entry_points():
     assert lib.gpvae_randn_b3(null, 6, 1, 2, one, 8) < 0          # count % 4 != 0
     assert lib.gpvae_randn_b3(null, 0, 1, 2, null, 0) == 0
     assert lib.gpvae_split_b3(null, 8, 8, 1, null, 8, 64, 0, one, 8, 64, 192) < 0  # X NULL
+    # fp16 x 2 entry points: the same shape rules, and every pointer is checked before a launch
+    assert lib.gpvae_potrf_h2(null, 300, 1, one, 300, 90000, one, 0, one, one, 304, 304 * 300, 2 * 304 * 300, one) == -2
+    assert b"gpvae_potrf_h2" in lib.gpvae_last_error()
+    assert lib.gpvae_potrf_h2(null, 512, 1, one, 512, 512 * 512, one, 0, one, one, 512, 512 * 512, 2 * 512 * 512, None) == -14  # inv_scale
+    assert lib.gpvae_potrf_h2(null, 512, 2, one, 512, 512 * 512, one, 0, one, one, 512, 512 * 512, 512 * 512, one) == -13    # stride2 < 2 planes
+    assert lib.gpvae_potrf_h2(null, 0, 1, null, 0, 0, null, 0, null, null, 0, 0, 0, None) == 0
+    assert lib.gpvae_potrf_h2_workspace_bytes(4096, 16) == 16 * 4096 * 64 * 4 + 256
+    assert lib.gpvae_draw_h2(null, 300, 256, one, 304, 304 * 300, one, one, 304, 256 * 304, null, 0, null, null, 0, one, 304) < 0
+    assert b"gpvae_draw_h2" in lib.gpvae_last_error()
+    assert lib.gpvae_randn_h2(null, 6, 1, 2, one, 8) < 0          # count % 4 != 0
+    assert lib.gpvae_split_h2(null, 8, 8, 1, null, 8, 64, 0, one, one, 8, 64, 128, one) < 0  # X NULL
     assert lib.gpvae_hyper_sample(null, 3, 4, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # dtype
     assert lib.gpvae_hyper_sample(null, 0, 4, 1, 2, 0, 7, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # prior id
     assert lib.gpvae_hyper_sample(null, 0, 0, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, null, null, null) == 0

@@ -285,3 +285,34 @@ def test_potrf_b3_and_draw_b3_random_shapes(ops):
             Y = ops.draw_b3(L3[b], E3, E2, 0.25)
             want = E3.float().sum(0).double() @ Ld.double().T + 0.25 * E2.double()
             assert rel(Y, want.cpu().numpy()) < 1e-6, tag + (b,)
+
+
+def test_potrf_h2_and_draw_h2_random_shapes(ops):
+    """The opt-in fp16 x 2 route over the same shapes, with matrix scales from 1e-3 to 1e3 (the planes' power-of-two
+    scale is chosen per matrix from its diagonal): factor against LAPACK, planes == factor * 2^e to 2^-21, draw from
+    the planes against a float64 product at the float32 bar."""
+    rng = np.random.default_rng(31)
+    for case in range(6):
+        n = int(rng.choice([512, 768, 1024, 1536]))
+        batch = int(rng.choice([1, 2, 7, 8, 9, 17]))
+        nb = int(rng.choice([128, 256, 384, 640]))
+        scale = 10 ** rng.uniform(-3, 3, batch)
+        A = spd(rng, batch, n) * scale[:, None, None]
+        Ad = padded(A, torch.float32, int(rng.choice([0, 4, 12])))
+        info, L2, inv = ops.potrf_h2_(Ad)
+        tag = (case, n, batch, nb)
+        assert (info == 0).all(), tag
+        for b in {0, batch // 2, batch - 1}:
+            Lo = np.linalg.cholesky(A[b])
+            Ld = torch.tril(Ad[b])
+            assert rel(Ld, Lo) < 2e-5, tag + (b, rel(Ld, Lo))
+            top = float(np.sqrt(A[b].diagonal().max()))
+            s = 1.0 / inv[b].item()
+            assert 2.0 ** 13 * (1 - 1e-6) < top * s <= 2.0 ** 14 * (1 + 1e-6), tag + (top, s)
+            back = torch.tril(L2[b].float().sum(0).double() / s)
+            assert ((back - Ld.double()).abs() <= 2.0 ** -21 * Ld.double().abs() + 2.0 ** -37 * top).all(), tag
+            E2h = ops.randn_h2((nb, n), DEV, seed=case, stream_id=b)
+            E2 = ops.randn((nb, n), torch.float32, DEV, seed=case, stream_id=100 + b)
+            Y = ops.draw_h2(L2[b], inv[b:b + 1], E2h, E2, 0.25 * top)
+            want = (E2h.float().sum(0).double() / 4096.0) @ Ld.double().T + 0.25 * top * E2.double()
+            assert rel(Y, want.cpu().numpy()) < 2e-6, tag + (b, rel(Y, want.cpu().numpy()))
