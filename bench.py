@@ -171,21 +171,6 @@ def extras(ops, x, dev):
                     "GB_per_s": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / PEAK_HBM_GBS,
                     "bound": "hbm write"}
         del Kb
-    # C3 again with the opt-in fp16 x 2 draw and factorisation (StepEngine(mfma="f16x2"): operands of the two
-    # matrix products rounded to 22 bits, errors at the float32 level — tests/test_gpu_seams.py::test_h2_*,
-    # test_potrf_h2_*): the same full training step as the headline, which stays on the operand-exact bf16 x 3
-    eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, hyper_sampler=bench_hyper, group=16, mfma="f16x2")
-    st = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
-    eng.run([(0, i) for i in range(20)], st, train=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run([(1, i) for i in range(400)], st, train=True)
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / 400
-    out["c3_f16x2"] = {"workload": "C3 full training step with mfma='f16x2' (opt-in: fp16 x 2 draw + factorisation)",
-                       "ms_per_step": t * 1e3, "draws_per_s": B / t, "sample": "400 steps after 20 warm-up steps",
-                       "failed_factors": eng.failed_factors()}
-    del eng, st
     # a2: aggregated (cell-averaged) kernel, 32 x 32 cells of 16 sample points each: 2.7e8 kernel evaluations
     # for a 4 MiB matrix — bound by the vector ALU's sqrt / exp issue, not by memory
     pa = ops.randn((1024, 16, 2), torch.float32, dev, seed=3) * 0.01 + x[::4, None, :].to(torch.float32)
@@ -256,6 +241,21 @@ def extras(ops, x, dev):
                       "wall_s": t, "chain_iterations_per_s": 1024 * 200 / t, "leapfrogs_per_iteration": lf,
                       "accept_prob": float(inf.mcmc_info["accept_prob"].mean().item()),
                       "divergent": int(inf.mcmc_info["divergent"])}
+    # C3 again with the opt-in fp16 x 2 draw and factorisation (StepEngine(mfma="f16x2"): operands of the two
+    # matrix products rounded to 22 bits, errors at the float32 level — tests/test_gpu_seams.py::test_h2_*,
+    # test_potrf_h2_*): the same full training step as the headline, which stays on the operand-exact bf16 x 3
+    eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, hyper_sampler=bench_hyper, group=16, mfma="f16x2")
+    st = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
+    eng.run([(0, i) for i in range(20)], st, train=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run([(1, i) for i in range(400)], st, train=True)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 400
+    out["c3_f16x2"] = {"workload": "C3 full training step with mfma='f16x2' (opt-in: fp16 x 2 draw + factorisation)",
+                       "ms_per_step": t * 1e3, "draws_per_s": B / t, "sample": "400 steps after 20 warm-up steps",
+                       "failed_factors": eng.failed_factors()}
+    del eng, st
     return out
 
 

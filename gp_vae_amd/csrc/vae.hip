@@ -34,8 +34,8 @@
 namespace gpvae {
 
 // ---- per-sample-block dense layers on the vector ALU ----------------------------------------------
-// RB = samples per workgroup in the mid kernels (a template parameter: 16 while the activation
-// buffers fit the 64 KB dynamic-LDS default, 4 or 2 for wide hidden layers; pick_rb below)
+// RB = samples per workgroup in the mid kernels (a template parameter: 16, 8 or 4 by the batch size while
+// the activation buffers fit the 64 KB dynamic-LDS default, 4 or 2 for wide hidden layers; pick_rb below)
 
 // out[r][j] = bias[j] + sum_k in[r][k] W[k*N + j]   (r < RB); in/out are LDS, W/bias global
 template <typename T, int RB>
@@ -670,10 +670,16 @@ static void dense_gemm_w(hipStream_t st, const T *A, int64_t M, int K, const T *
 
 // samples per workgroup of the mid kernels: the backward kernel keeps four [RB][mx] buffers in LDS and a
 // launch may ask for 64 KB of it; h0, h1, z <= 1024 (check_dims) always leaves RB >= 2
-template <typename T> static inline int pick_rb(int mx, int nbuf) {
+// Among the sizes that fit, the largest that still gives two workgroups per CU (the kernels are latency-bound:
+// at C3, B = 4096, the ELBO takes 200 / 192 / 195 us with 16 / 8 / 4 samples per workgroup), else 4.
+template <typename T> static inline int pick_rb(int mx, int nbuf, int64_t rows) {
+  int fit = 0;
   for (int rb : {16, 8, 4, 2})
-    if ((size_t)nbuf * rb * mx * sizeof(T) <= 64 * 1024) return rb;
-  return 0;
+    if ((size_t)nbuf * rb * mx * sizeof(T) <= 64 * 1024) {
+      if (fit == 0) fit = rb;
+      if (rb <= 4 || cdiv(rows, (int64_t)rb) >= 512) return rb;
+    }
+  return fit;
 }
 #define GPVAE_RB_SWITCH(rb, ...)                                   \
   switch (rb) {                                                    \
@@ -701,7 +707,7 @@ template <typename T> struct ElboPlan {
     const int mx = std::max(h0, std::max(h1, z));
     mc = VaeParams<T>::mid_count(h0, h1, z);
     const size_t mid_bytes = (size_t)mc * sizeof(T);
-    rb = pick_rb<T>(mx, 4);
+    rb = pick_rb<T>(mx, 4, B);
     wide = rb == 0 || mid_bytes + 4 * (size_t)rb * mx * sizeof(T) > 60 * 1024;
     nblk = cdiv(B, rb > 0 ? rb : 1);
     fused_dims = sizeof(T) == 4 && h0 + 1 <= 64 && B % 128 == 0 && n % 64 == 0 &&
@@ -921,7 +927,7 @@ static int run_decoder(hipStream_t st, bool vjp, int64_t C, int64_t n, int h0, i
   VaeDims<T> dims{C, n, h0, h1, z};
   const int mx = std::max(h0, std::max(h1, z));
   // as in run_vae_elbo: per-sample-block kernels for the reference's small heads, tile products when wide
-  const int rb = pick_rb<T>(mx, 2);
+  const int rb = pick_rb<T>(mx, 2, C);
   const bool wide = rb == 0 || (int64_t)z * h1 + (int64_t)h1 * h0 > 8192;
   const size_t shm = 2 * (size_t)rb * mx * sizeof(T);
   const unsigned nblk = (unsigned)cdiv(C, rb > 0 ? rb : 1);
