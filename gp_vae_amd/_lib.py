@@ -45,6 +45,7 @@ SIGNATURES = {
     "gpvae_draw_b3": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64,
                            _vp, _i64]),
     "gpvae_hyper_sample": (_i, [_vp, _i, _i64, _u64, _u64, _i64, _i, _d, _d, _d, _d, _vp, _vp, _vp]),
+    "gpvae_poisson_exp": (_i, [_vp, _i, _i64, _u64, _u64, _i64, _vp, _vp, _vp]),
     "gpvae_krig_workspace_bytes": (_i64, [_i, _i64, _i64]),
     "gpvae_krig_predict": (_i, [_vp, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp,
                                 _vp, _vp, _vp, _vp, _vp]),

@@ -212,6 +212,54 @@ __global__ void hyper_sample_kernel(int64_t count, uint64_t seed, uint64_t strea
   }
 }
 
+// ---- f4: the LGCP observation of PoiGP.sample (gp.py:249-250): rate = exp(f), y ~ Poisson(rate) -------------
+// One Philox counter per (element, attempt), as above.  rate < 10: inversion by sequential search on one uniform;
+// rate >= 10: Hoermann's transformed rejection (PTRS, 1993 — the method NumPy and JAX use), two uniforms per
+// attempt.  Arithmetic in double on the rate rounded to T.  y is int32 (JAX's default integer): -1 for a rate
+// that is NaN or negative, 2^31 - 1 for rates beyond 2^31 - 1 (exp(f) overflowing included).
+__device__ inline int32_t poisson_draw(double lam, const HyperRng &r) {
+  if (!(lam >= 0.0)) return -1;
+  if (lam == 0.0) return 0;
+  if (lam > 2147483647.0) return 2147483647;
+  uint32_t c[4];
+  if (lam < 10.0) {
+    r.words(7, 0, c);
+    const double u = HyperRng::unif(c[0]);
+    double p = exp(-lam), s = p;
+    int k = 0;
+    while (u > s && k < 200) {
+      ++k;
+      p *= lam / (double)k;
+      s += p;
+    }
+    return k;
+  }
+  const double slam = sqrt(lam), loglam = log(lam);
+  const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+  const double inv_alpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+  for (uint32_t att = 0; att < 64; ++att) {
+    r.words(7, att, c);
+    const double U = HyperRng::unif(c[0]) - 0.5, V = HyperRng::unif(c[1]);
+    const double us = 0.5 - fabs(U);
+    const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+    if (us >= 0.07 && V <= vr) return (int32_t)fmin(kf, 2147483647.0);
+    if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+    if (log(V) + log(inv_alpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0))
+      return (int32_t)fmin(kf, 2147483647.0);
+  }
+  return (int32_t)fmin(floor(lam), 2147483647.0);  // 64 rejections in a row: probability < 1e-30
+}
+
+template <typename T>
+__global__ void poisson_exp_kernel(int64_t count, uint64_t seed, uint64_t stream_id, uint32_t first, const T *f,
+                                   T *rate, int32_t *y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const T rt = (T)exp((double)f[i]);  // correctly rounded to T but for double's own last bit
+  if (rate) rate[i] = rt;
+  if (y) y[i] = poisson_draw((double)rt, HyperRng{seed, stream_id, first + (uint32_t)i});
+}
+
 template <typename T>
 __global__ void randn_kernel(int64_t count, uint64_t seed, uint64_t stream_id, T *out) {
   const int64_t nq = (count + 3) / 4;
@@ -328,6 +376,26 @@ extern "C" int gpvae_randn(void *stream, int dtype, int64_t count, uint64_t seed
     hipLaunchKernelGGL((randn_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, count,
                        seed, stream_id, (double *)out);
   GPVAE_CHECK_LAUNCH("gpvae_randn");
+  return 0;
+}
+
+extern "C" int gpvae_poisson_exp(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
+                                 int64_t first_index, const void *f, void *rate, int32_t *y) {
+  GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_poisson_exp: bad dtype %d", dtype);
+  GPVAE_REQUIRE(count >= 0, 3, "gpvae_poisson_exp: count < 0");
+  GPVAE_REQUIRE(first_index >= 0 && first_index + count <= 0xffffffffLL, 6, "gpvae_poisson_exp: element indices must fit 32 bits");
+  if (count == 0) return 0;
+  GPVAE_REQUIRE(f, 7, "gpvae_poisson_exp: f is NULL");
+  GPVAE_REQUIRE(rate || y, 9, "gpvae_poisson_exp: both rate and y are NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)cdiv(count, 256));
+  if (dtype == GPVAE_F32)
+    hipLaunchKernelGGL((poisson_exp_kernel<float>), grid, dim3(256), 0, st, count, seed, stream_id, (uint32_t)first_index,
+                       (const float *)f, (float *)rate, y);
+  else
+    hipLaunchKernelGGL((poisson_exp_kernel<double>), grid, dim3(256), 0, st, count, seed, stream_id, (uint32_t)first_index,
+                       (const double *)f, (double *)rate, y);
+  GPVAE_CHECK_LAUNCH("gpvae_poisson_exp");
   return 0;
 }
 

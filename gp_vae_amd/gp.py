@@ -168,6 +168,73 @@ class GP():
         return out
 
 
+def _agg_points(rng_key, d, m, grid1, grid2=None):
+    """The cells' Monte-Carlo sample points [n^d, m, d] of agg_kernel_grid (gp.py:98-113)."""
+    grid1 = _as_device(grid1)
+    n = grid1.shape[0]
+    gen = torch.Generator(device=grid1.device)
+    gen.manual_seed(_seed_of(rng_key))
+    u = torch.rand((n ** d, m, d), generator=gen, device=grid1.device, dtype=grid1.dtype)
+    if d == 1:
+        return u / n + grid1[:, None, None]
+    g2 = grid1 if grid2 is None else _as_device(grid2, grid1.dtype)
+    uu, vv = torch.meshgrid(grid1, g2, indexing="xy")
+    return u / n + torch.stack([uu.flatten(), vv.flatten()], dim=1)[:, None, :]
+
+
+class PoiGP(GP):
+    """Log-Gaussian Cox process prior on a [0,1]^d grid (gp.py:197-250) with the reference's argument list:
+    k = agg_kernel_grid(PRNGKey(seed), d, m, kernel, var, ls, x1, x2, jitter); f ~ MVN(0, k); rate = exp(f);
+    y ~ Poisson(rate) — no observation noise (`sigma` is accepted and ignored, gp.py:228-229,248).
+
+    The reference's method does not run as written (`grid1.shape()`, a loc of n instead of n^d
+    entries in 2-D); this is the evident intent: n = x1.shape[0] cells per axis, f over all n^d cells.  Under
+    Predictive the hyper-parameters left None are drawn per sample (sites `length`, `var`), the cells' sample
+    points come from `seed` and are therefore the same for every sample, as in the reference."""
+
+    def sample(self, m, x1, x2=None, y=None, ls=None, var=None, sigma=None, seed=0, rng_key=None, num_samples=1):
+        if self.kernel is not exp_kernel2:
+            raise NotImplementedError("PoiGP is built for exp_kernel2 only")
+        if self.d not in (1, 2):
+            raise Warning("Function is only implemented for d=1,2")  # gp.py:117
+        x1 = _as_device(x1)
+        pts = _agg_points(seed, self.d, int(m), x1, x2)
+        cells, B = pts.shape[0], int(num_samples)
+        kseed, base = _key_parts(rng_key)
+        E = ops.randn((B, cells), x1.dtype, x1.device, seed=kseed, stream_id=base | 1)
+        out = {}
+        if ls is not None and var is not None:
+            K = ops.gram_agg(pts, var, ls, self.jitter)
+            self.last_info = ops.potrf_(K)
+            F = ops.draw(K, E)
+        else:
+            rng = np.random.default_rng(kseed if base == 0 else [kseed, base])
+            ls_s, var_s, _ = draw_hyper(rng, B)
+            if ls is not None:
+                ls_s = np.full(B, float(ls))
+            else:
+                out["length"] = torch.as_tensor(ls_s, dtype=x1.dtype, device=x1.device)
+            if var is not None:
+                var_s = np.full(B, float(var))
+            else:
+                out["var"] = torch.as_tensor(var_s, dtype=x1.dtype, device=x1.device)
+            # B distinct aggregated kernels: one gpvae_gram_agg each, ONE batched factor sweep and one
+            # batched-factor draw per chunk of samples (chunks bound the factors to ~2 GiB)
+            F = torch.empty((B, cells), dtype=x1.dtype, device=x1.device)
+            per = max(1, min(B, int(2 ** 31 // max(1, cells * cells * x1.element_size()))))
+            infos = []
+            for lo in range(0, B, per):
+                hi = min(B, lo + per)
+                Kb = torch.stack([ops.gram_agg(pts, float(var_s[i]), float(ls_s[i]), self.jitter) for i in range(lo, hi)])
+                infos.append(ops.potrf_(Kb))
+                F[lo:hi] = ops.draw_batched(Kb, E[lo:hi])
+            self.last_info = torch.cat(infos)
+        rate, counts = ops.poisson_exp(F, seed=kseed, stream_id=base | 4)
+        out["f"], out["rate"] = F, rate
+        out["y"] = counts if y is None else _as_device(y).expand(B, cells)
+        return out
+
+
 class Predictive():
     """Call-compatible stand-in for numpyro.infer.Predictive at the reference's call sites:
       Predictive(gp.sample, num_samples=B)(rng_key, x=x, ls=..., var=..., sigma=...) -> {'y': [B,n], 'f', ...}

@@ -306,6 +306,19 @@ def hyper_sample(count, dtype=torch.float32, device="cuda", seed=0, stream_id=0,
     return out[1, :count], out[0, :count], out[2, :count]
 
 
+def poisson_exp(f, seed=0, stream_id=0, first_index=0, want_y=True):
+    """rate = exp(f) and y ~ Poisson(rate) (int32) elementwise: the observation of PoiGP.sample (gp.py:249-250).
+    Element i of the flattened f draws from Philox counter first_index + i of (seed, stream_id).
+    Returns (rate, y) shaped like f (y None when want_y is False)."""
+    _dev(f)
+    f = f.contiguous()
+    rate = torch.empty_like(f)
+    y = torch.empty(f.shape, dtype=torch.int32, device=f.device) if want_y else None
+    check(_lib.load().gpvae_poisson_exp(_stream(), _dt(f), f.numel(), int(seed), int(stream_id), int(first_index),
+                                        _p(f), _p(rate), _p(y)), "gpvae_poisson_exp")
+    return rate, y
+
+
 # ---- bf16 x 3 (b3) operands: three bf16 planes that sum to the float exactly --------------------------
 def split_b3(X, lower=False, out=None):
     """float32 X [rows, cols] or [batch, rows, cols] -> bf16 planes [3, rows, cols] / [batch, 3, rows, cols]

@@ -206,6 +206,16 @@ int gpvae_hyper_sample(void *stream, int dtype, int64_t count, uint64_t seed, ui
                        int64_t first_index, int ls_prior, double ls_a, double ls_b, double var_scale,
                        double sigma_scale, void *ls, void *var, void *sigma);
 
+/* ---- f4: the LGCP observation of PoiGP.sample ------------------------------------------------------
+ * Replaces `rate = exp(f); numpyro.sample("y", dist.Poisson(rate))` (src/model/gp.py:249-250) for
+ * count elements: rate[i] = exp(f[i]) (dtype), y[i] ~ Poisson(rate[i]) (int32, JAX's default integer).
+ * Element i draws from the Philox4x32-10 counters (first_index + i, attempt) of (seed, stream_id), so a
+ * sample does not depend on how calls are batched: inversion for rate < 10, Hoermann's transformed
+ * rejection (PTRS) above.  y = -1 where the rate is NaN, 2^31 - 1 where it exceeds that.  rate or y
+ * may be NULL.  Stands in for JAX's threefry stream like gpvae_randn.                               */
+int gpvae_poisson_exp(void *stream, int dtype, int64_t count, uint64_t seed, uint64_t stream_id,
+                      int64_t first_index, const void *f, void *rate, int32_t *y);
+
 /* ---- a9: kriging prediction ---------------------------------------------------------------------
  * Replaces GPInference.gp_prediction (src/model/inference.py:427-460), literal quirks kept:
  *   A = k_xx + jitter*I + sigma*I   (sigma, not sigma^2: inference.py:450)

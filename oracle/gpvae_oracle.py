@@ -410,6 +410,66 @@ def hyper_sample(count, seed=0, stream_id=0, first_index=0, ls_prior="invgamma",
     return ls, var, sig
 
 
+def _poisson_one(lam, idx, seed, stream_id):
+    """One Poisson(lam) draw from the Philox words of counter (idx, 7 << 24 | attempt): inversion by sequential
+    search below 10, Hoermann's PTRS (1993; NumPy's and JAX's method) from 10 up — gpvae_poisson_exp's sampler."""
+    import math
+    if not lam >= 0.0:
+        return -1
+    if lam == 0.0:
+        return 0
+    if lam > 2147483647.0:
+        return 2147483647
+    if lam < 10.0:
+        u = _unif(_hyper_words(idx, 7, 0, seed, stream_id)[0])
+        p = math.exp(-lam)
+        s, k = p, 0
+        while u > s and k < 200:
+            k += 1
+            p *= lam / k
+            s += p
+        return k
+    slam, loglam = math.sqrt(lam), math.log(lam)
+    b = 0.931 + 2.53 * slam
+    a = -0.059 + 0.02483 * b
+    inv_alpha = 1.1239 + 1.1328 / (b - 3.4)
+    vr = 0.9277 - 3.6224 / (b - 2.0)
+    for att in range(64):
+        c = _hyper_words(idx, 7, att, seed, stream_id)
+        U, V = _unif(c[0]) - 0.5, _unif(c[1])
+        us = 0.5 - abs(U)
+        kf = math.floor((2.0 * a / us + b) * U + lam + 0.43)
+        if us >= 0.07 and V <= vr:
+            return int(min(kf, 2147483647))
+        if kf < 0 or (us < 0.013 and V > us):
+            continue
+        if math.log(V) + math.log(inv_alpha) - math.log(a / (us * us) + b) <= -lam + kf * loglam - math.lgamma(kf + 1.0):
+            return int(min(kf, 2147483647))
+    return int(min(math.floor(lam), 2147483647))
+
+
+def poisson_exp(f, seed=0, stream_id=0, first_index=0, rate=None):
+    """rate = exp(f) (in f's dtype) and y ~ Poisson(rate), int32: the observation of PoiGP.sample
+    (gp.py:249-250: `rate = exp(f)`, `y ~ Poisson(rate)`), element i from Philox counter first_index + i.
+    `rate` overrides exp(f) (tests hand over the device's rates so that the draws compare bit for bit)."""
+    f = np.asarray(f)
+    with np.errstate(over="ignore"):
+        rt = np.exp(f.astype(np.float64)).astype(f.dtype) if rate is None else np.asarray(rate)
+    y = np.array([_poisson_one(float(r), first_index + i, seed, stream_id) for i, r in enumerate(rt.reshape(-1))],
+                 dtype=np.int32).reshape(rt.shape)
+    return rt, y
+
+
+def poigp_sample(pts, var, ls, eps, jitter, seed=0, stream_id=0):
+    """PoiGP.sample with the hyper-parameters given (gp.py:234-250): k = aggregated kernel of the cells'
+    sample points, f = chol(k) eps (MultivariateNormal's draw), rate = exp(f), y ~ Poisson(rate).
+    pts [cells, m, d], eps [B, cells].  Returns f, rate, y."""
+    k = agg_kernel_from_points(pts, var, ls, jitter)
+    f = gp_draw(cholesky_lower(k), eps)[0]
+    rate, y = poisson_exp(f, seed, stream_id)
+    return f, rate, y
+
+
 def train_step(p, m, v, t, x, hyper, eps, eps2, eps_z, lr, jitter, obs_sigma=0.1):
     """One body_fn of VAE.epoch_train (vae.py:150-167) with every random input explicit."""
     ls, var, sigma = hyper

@@ -32,7 +32,7 @@ def test_exported_symbols_equal_declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = header_symbols()
-    assert len(names) == 44
+    assert len(names) == 45
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
@@ -113,6 +113,10 @@ def test_argument_validation_of_the_round_2_entry_points():
     assert b"gpvae_draw_h2" in lib.gpvae_last_error()
     assert lib.gpvae_randn_h2(null, 6, 1, 2, one, 8) < 0          # count % 4 != 0
     assert lib.gpvae_split_h2(null, 8, 8, 1, null, 8, 64, 0, one, one, 8, 64, 128, one) < 0  # X NULL
+    assert lib.gpvae_poisson_exp(null, 7, 4, 1, 2, 0, one, one, one) == -2                          # dtype
+    assert lib.gpvae_poisson_exp(null, 0, 4, 1, 2, 2 ** 32, one, one, one) == -6                    # index range
+    assert lib.gpvae_poisson_exp(null, 0, 4, 1, 2, 0, one, null, null) == -9                        # nothing to write
+    assert lib.gpvae_poisson_exp(null, 0, 0, 1, 2, 0, null, null, null) == 0
     assert lib.gpvae_hyper_sample(null, 3, 4, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # dtype
     assert lib.gpvae_hyper_sample(null, 0, 4, 1, 2, 0, 7, 1.0, 0.1, 0.1, 0.1, one, one, one) < 0   # prior id
     assert lib.gpvae_hyper_sample(null, 0, 0, 1, 2, 0, 0, 1.0, 0.1, 0.1, 0.1, null, null, null) == 0

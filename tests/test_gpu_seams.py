@@ -592,3 +592,68 @@ def test_potrf_h2_factor_and_planes():
         info2, L22, inv2 = ops.potrf_h2_(A2, nan_on_fail=True)
         assert torch.isnan(ops.draw_h2(L22[1], inv2[1:2], ops.randn_h2((256, n), DEV, seed=1))).all()
         assert not torch.isnan(ops.draw_h2(L22[0], inv2[0:1], ops.randn_h2((256, n), DEV, seed=1))).any()
+
+
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-14), (torch.float32, np.float32, 2e-7)])
+def test_poisson_exp_matches_oracle(tdt, ndt, tol):
+    """gpvae_poisson_exp (rate = exp(f), y ~ Poisson(rate): gp.py:249-250): rates to rounding, counts BIT-EXACT
+    against the oracle's restatement of the sampler on the same rates, edge values, batching independence."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(23)
+    f = np.concatenate([rng.uniform(-7, 2.25, 3000), rng.uniform(2.35, 12, 3000), [-np.inf, 0.0, 25.0, 1000.0, np.nan]]).astype(ndt)
+    ft = torch.tensor(f, device=DEV)
+    rate, y = ops.poisson_exp(ft, seed=77, stream_id=5)
+    rt, yt = rate.cpu().numpy(), y.cpu().numpy()
+    want_rate, _ = orc.poisson_exp(f, 77, 5)
+    fin = np.isfinite(want_rate)
+    assert np.allclose(rt[fin], want_rate[fin], rtol=tol, atol=0) and np.isinf(rt[-2]) and np.isnan(rt[-1]) and rt[-5] == 0
+    _, want_y = orc.poisson_exp(f, 77, 5, rate=rt)   # the sampler on the device's own rates: integer parity
+    assert y.dtype == torch.int32 and np.array_equal(yt, want_y)
+    assert yt[-1] == -1 and yt[-2] == 2 ** 31 - 1 and yt[-5] == 0
+    # both branches are exercised and the counts follow their rates
+    small, large = rt[:3000], rt[3000:6000]
+    assert small.max() < 10 < large.min() and abs((yt[:3000] - small).sum()) < 5 * math.sqrt(small.sum())
+    assert abs((yt[3000:6000] - large).sum()) < 5 * math.sqrt(large.sum())
+    # element i depends on first_index + i only
+    _, y2 = ops.poisson_exp(ft[4000:], seed=77, stream_id=5, first_index=4000)
+    assert torch.equal(y2, y[4000:])
+    assert ops.poisson_exp(ft[:0], seed=1)[1].numel() == 0
+
+
+@pytest.mark.parametrize("tdt,ndt,tol", [(torch.float64, np.float64, 1e-9), (torch.float32, np.float32, 2e-4)])
+def test_poigp_sample_against_oracle(tdt, ndt, tol):
+    """PoiGP.sample (gp.py:197-250) behind Predictive: with the hyper-parameters given, f / rate / y against
+    oracle.poigp_sample on the same sample points and normals (1-D and 2-D grids); with them left None, the
+    `length` / `var` sites, one aggregated kernel per sample, counts that follow their rates."""
+    from gp_vae_amd import ops, gp as gpm
+    for d, n, m, B, ls in ((1, 24, 6, 64, 0.05), (2, 5, 4, 32, 0.15)):
+        grid = torch.arange(n, dtype=tdt, device=DEV) / n
+        prior = gpm.PoiGP(kernel=gpm.exp_kernel2, jitter=1e-4, d=d)
+        key = gpm.PhiloxKey(9, base=0x30)
+        out = gpm.Predictive(prior.sample, num_samples=B)(key, m, grid, ls=ls, var=0.7, seed=4)
+        cells = n ** d
+        assert out["f"].shape == (B, cells) and out["y"].dtype == torch.int32 and int(prior.last_info.item()) == 0
+        pts = gpm._agg_points(4, d, m, grid).cpu().numpy()
+        eps = ops.randn((B, cells), tdt, DEV, seed=9, stream_id=0x31).cpu().numpy().astype(np.float64)
+        f, _, _ = orc.poigp_sample(pts.astype(np.float64), 0.7, ls, eps, 1e-4)
+        assert rel(out["f"], f) < tol, (d, rel(out["f"], f))
+        rt = out["rate"].cpu().numpy()
+        assert np.allclose(rt, np.exp(out["f"].cpu().numpy().astype(np.float64)), rtol=10 * np.finfo(ndt).eps)
+        _, want_y = orc.poisson_exp(out["f"].cpu().numpy(), 9, 0x34, rate=rt)
+        assert np.array_equal(out["y"].cpu().numpy(), want_y)
+        # observed counts are passed through (numpyro's obs=)
+        obs = torch.ones(cells, dtype=torch.int32, device=DEV)
+        assert torch.equal(prior.sample(m, grid, y=obs, ls=ls, var=0.7, rng_key=key, num_samples=2)["y"], obs.expand(2, cells))
+        # hyper-parameters left None: per-sample sites and kernels.  The aggregated kernel carries no diagonal
+        # jitter (gp.py:119-127 adds it to every entry), so the long length scales of InverseGamma(1, 0.1) give
+        # matrices that are not positive definite: NaN draws as in the reference, counts -1
+        out2 = gpm.Predictive(prior.sample, num_samples=B)(key, m, grid, seed=4)
+        assert out2["length"].shape == (B,) and out2["var"].shape == (B,)
+        good = prior.last_info == 0
+        assert good.sum().item() >= B // 8
+        assert torch.isnan(out2["f"][~good]).all() and (out2["y"][~good] == -1).all()
+        i = int(torch.where(good, out2["length"], torch.full_like(out2["length"], 1e9)).argmin().item())  # best conditioned
+        f_i, _, _ = orc.poigp_sample(pts.astype(np.float64), float(out2["var"][i]), float(out2["length"][i]), eps[i:i + 1], 1e-4)
+        assert rel(out2["f"][i:i + 1], f_i) < 50 * tol
+        tot, lam = out2["y"][good].double().sum().item(), out2["rate"][good].double().sum().item()
+        assert (out2["y"][good] >= 0).all() and abs(tot - lam) < 6 * math.sqrt(lam)

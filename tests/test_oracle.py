@@ -257,3 +257,41 @@ def test_philox_hyper_prior_samplers():
     assert abs(l4.mean() - 1 / 3.0) < 0.01                                   # InverseGamma(4, 1): b/(a-1)
     a = orc.hyper_sample(10, seed=3, stream_id=9, first_index=100)
     assert all(np.array_equal(u, v[100:110]) for u, v in zip(a, orc.hyper_sample(110, seed=3, stream_id=9)))
+
+
+def test_poisson_sampler_against_scipy():
+    """The Philox Poisson sampler (inversion below 10, PTRS above; the observation of PoiGP.sample, gp.py:249-250):
+    chi-square against scipy's pmf on both branches, moments at large rates, and the edge values."""
+    for lam in (0.4, 4.0, 9.99, 10.0, 37.5):
+        y = np.array([orc._poisson_one(lam, i, 11, 3) for i in range(12000)])
+        hi = int(sst.poisson.ppf(1 - 1e-4, lam)) + 1
+        obs = np.bincount(np.minimum(y, hi), minlength=hi + 1).astype(float)
+        pmf = sst.poisson.pmf(np.arange(hi + 1), lam)
+        pmf[hi] = sst.poisson.sf(hi - 1, lam)
+        keep = pmf * len(y) >= 5
+        obs_k, exp_k = np.append(obs[keep], obs[~keep].sum()), np.append(pmf[keep], pmf[~keep].sum()) * len(y)
+        ok = exp_k > 0
+        chi2 = ((obs_k[ok] - exp_k[ok]) ** 2 / exp_k[ok]).sum()
+        assert chi2 < sst.chi2.ppf(1 - 1e-4, ok.sum() - 1), (lam, chi2)
+    y = np.array([orc._poisson_one(5000.0, i, 1, 1) for i in range(8000)])
+    assert abs(y.mean() - 5000.0) < 5 * np.sqrt(5000.0 / 8000) and abs(y.var() / 5000.0 - 1) < 0.08
+    assert orc._poisson_one(float("nan"), 0, 0, 0) == -1 and orc._poisson_one(-1.0, 0, 0, 0) == -1
+    assert orc._poisson_one(0.0, 0, 0, 0) == 0 and orc._poisson_one(float("inf"), 0, 0, 0) == 2 ** 31 - 1
+    # batching: element i depends on (first_index + i) only
+    f = np.linspace(-3, 4, 40)
+    r, ya = orc.poisson_exp(f, 7, 2)
+    _, yb = orc.poisson_exp(f[25:], 7, 2, first_index=25)
+    assert np.array_equal(ya[25:], yb) and np.allclose(r, np.exp(f))
+
+
+def test_poigp_prior_draw_moments():
+    """oracle.poigp_sample: f has the aggregated kernel's covariance and E[y | f] = exp(f)."""
+    rng = np.random.default_rng(3)
+    grid = np.arange(0, 1, 1 / 6)
+    pts = orc.agg_points(rng.random((6, 5, 1)), grid, d=1)
+    k = orc.agg_kernel_from_points(pts, 0.8, 0.3, 1e-4)
+    eps = rng.standard_normal((20000, 6))
+    f, rate, y = orc.poigp_sample(pts, 0.8, 0.3, eps, 1e-4, seed=5)
+    assert np.abs(np.cov(f.T) - k).max() < 0.04
+    assert np.allclose(rate, np.exp(f)) and (y >= 0).all()
+    assert abs((y - rate).mean()) < 5 * np.sqrt(rate.mean() / y.size)
