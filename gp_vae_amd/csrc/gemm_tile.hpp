@@ -24,21 +24,21 @@ template <typename T> struct GemmArgs {
   const T *Yref;        // EPI_DF: data, ld = ldy
   int64_t ldy;
   T inv_var;            // EPI_DF: 1/obs_sigma^2
-  T *loss;              // EPI_DF: += 0.5 * sum diff^2 * inv_var
+  T *loss;              // (unused: the loss parts go to loss_part)
   int vec_a, vec_b;
   int trans_c;          // store C transposed: C[col * ldc + row] (EPI_STORE / EPI_ATOMIC)
   // EPI_FUSED (the dense layers of the wide-MLP path, the solve's updates):
   // C = mask(relu([C +/-] A B [+ bias])); mask may alias C (each element is read before it is
   // written, by the same lane)
   int addc, relu;
-  int negate;           // C - A B (EPI_FUSED with addc, EPI_ATOMIC)
+  int negate;           // C - A B (EPI_FUSED with addc), -A B (EPI_ATOMIC)
   const T *mask;        // keep where mask > 0, else 0 (nullptr: keep all)
   int64_t ldm;
-  // EPI_ATOMIC with slab > 0: k-slice z STORES its partial tile at C[z * slab + index] instead of adding
-  // it to C with float atomics; the caller sums the slices in a fixed order (slab_sum_kernel, or the
-  // consumer itself) — the same bits on every run
+  // EPI_ATOMIC (the name is historical: no atomics are left): k-slice z STORES its partial tile at
+  // C[z * slab + index]; the caller sums the slices in a fixed order (slab_sum_kernel, or the consumer
+  // itself) — the same bits on every run.  slab must be set.
   int64_t slab = 0;
-  T *loss_part = nullptr;  // EPI_DF: workgroup w stores its part of the loss at loss_part[w] (no atomic)
+  T *loss_part = nullptr;  // EPI_DF: workgroup w stores its part of the loss at loss_part[w]; must be set
 };
 
 constexpr int GBM = 128, GBN = 64;
@@ -184,11 +184,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
         if constexpr (EPI == EPI_STORE) {
           if (in) g.C[ci] = v;
         } else if constexpr (EPI == EPI_ATOMIC) {
-          if (g.slab > 0) {
-            if (in) g.C[(int64_t)blockIdx.z * g.slab + ci] = g.negate ? -v : v;
-          } else if (in) {
-            atomicAdd(&g.C[ci], g.negate ? -v : v);
-          }
+          if (in) g.C[(int64_t)blockIdx.z * g.slab + ci] = g.negate ? -v : v;
         } else if constexpr (EPI == EPI_BIAS) {
           if (in) g.C[row * g.ldc + col] = v + g.bias[col];
         } else if constexpr (EPI == EPI_FUSED) {
@@ -216,8 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs<T> g) {
     __syncthreads();
     if (tid == 0) {
       const T part = T(0.5) * g.inv_var * (red[0] + red[1] + red[2] + red[3]);
-      if (g.loss_part != nullptr) g.loss_part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = part;
-      else atomicAdd(g.loss, part);
+      g.loss_part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = part;
     }
   }
 }

@@ -8,24 +8,17 @@
 //
 //   trans = 1:  X <- X L^-T   (every row x of X becomes the y with L y = x:   forward substitution)
 //   trans = 0:  X <- X L^-1   (every row x of X becomes the y with L^T y = x: backward substitution)
-// so X L^-T L^-1 = X A^-1 for A = L L^T.  Blocked by 64 columns: the columns already solved update
-// the current block through the generic tile product (MFMA, split over K, partial sums subtracted
-// with atomics), then each row finishes its 64 unknowns against the diagonal block held in LDS.
-// The update is "sum the products, subtract from C" — fine for a solve against a given factor (the
+// so X L^-T L^-1 = X A^-1 for A = L L^T.  Blocked by 64 columns, right-looking: each row finishes the 64
+// unknowns of a block against the diagonal block held in LDS, then the block just solved updates every
+// column still to come through the generic tile product, X_rest -= X_block L_rest,block^T (K = 64, no split
+// over K: every element of X is written by one lane — no atomics, the same bits on every call).
+// The update is "subtract the product from C" block by block — fine for a solve against a given factor (the
 // ordering that matters on nearly singular matrices is the factorisation's, potrf.hip).
 #include "gemm_tile.hpp"
 
 namespace gpvae {
 
 constexpr int TSB = 64;  // column block
-
-// k slices so that a launch has about 512 workgroups, at least 4 k-tiles each
-static inline int pick_splitk(int64_t tiles, int64_t K) {
-  int64_t s = 512 / (tiles > 0 ? tiles : 1);
-  const int64_t maxs = cdiv(K, 4 * 32);
-  if (s > maxs) s = maxs;
-  return (int)(s < 1 ? 1 : s);
-}
 
 // rows [row0, row0+256) of X, columns [c0, c0+w): finish the solve against the diagonal block of L
 template <typename T, bool TRANS>
@@ -85,26 +78,28 @@ static int run_trsm(hipStream_t st, int trans, int64_t n, int64_t m, const void 
     const int64_t j = trans ? jb : nb - 1 - jb;  // forward / backward over the column blocks
     const int64_t c0 = j * TSB;
     const int w = (int)((c0 + TSB <= n) ? TSB : n - c0);
-    GemmArgs<T> g{};
-    g.C = X + c0; g.ldc = ldx; g.M = m; g.N = w; g.negate = 1;  // partial sums subtracted by atomics
-    g.a_ones_row = -1; g.b_ones_row = -1;
-    if (trans && c0 > 0) {
-      // X[:, c0:c0+w] -= X[:, :c0] L[c0:c0+w, :c0]^T      (both operands K-contiguous)
-      g.A = X; g.lda = ldx; g.B = L + c0 * ldl; g.ldb = ldl; g.K = c0;
-      g.vec_a = kc_vec_ok<T>(X, ldx); g.vec_b = kc_vec_ok<T>(g.B, ldl);
-      launch_gemm<T, true, true, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(m, 64), g.K));
-    } else if (!trans && c0 + w < n) {
-      // X[:, c0:c0+w] -= X[:, c0+w:] L[c0+w:, c0:c0+w]    (B is N-contiguous)
-      g.A = X + c0 + w; g.lda = ldx; g.B = L + (c0 + w) * ldl + c0; g.ldb = ldl; g.K = n - c0 - w;
-      g.vec_a = kc_vec_ok<T>(g.A, ldx); g.vec_b = mc_vec_ok<T>(g.B, ldl);
-      launch_gemm<T, true, false, EPI_ATOMIC, 64>(st, g, pick_splitk(cdiv(m, 64), g.K));
-    }
     if (trans)
       hipLaunchKernelGGL((trsm_diag_kernel<T, true>), dim3(dgrid), dim3(NTHREADS), 0, st, m, w,
                          L + c0 * ldl + c0, ldl, X + c0, ldx);
     else
       hipLaunchKernelGGL((trsm_diag_kernel<T, false>), dim3(dgrid), dim3(NTHREADS), 0, st, m, w,
                          L + c0 * ldl + c0, ldl, X + c0, ldx);
+    GemmArgs<T> g{};
+    g.A = X + c0; g.lda = ldx; g.K = w; g.M = m; g.ldc = ldx;
+    g.addc = 1; g.negate = 1;  // C - A B, one k-slice: plain read-modify-write by the owning lane
+    g.a_ones_row = -1; g.b_ones_row = -1;
+    g.vec_a = kc_vec_ok<T>(g.A, ldx);
+    if (trans && c0 + w < n) {
+      // X[:, c0+w:] -= X[:, c0:c0+w] L[c0+w:, c0:c0+w]^T      (both operands K-contiguous)
+      g.B = L + (c0 + w) * ldl + c0; g.ldb = ldl; g.C = X + c0 + w; g.N = n - c0 - w;
+      g.vec_b = kc_vec_ok<T>(g.B, ldl);
+      launch_gemm<T, true, true, EPI_FUSED>(st, g, 1);
+    } else if (!trans && c0 > 0) {
+      // X[:, :c0] -= X[:, c0:c0+w] L[c0:c0+w, :c0]           (B is N-contiguous)
+      g.B = L + c0 * ldl; g.ldb = ldl; g.C = X; g.N = c0;
+      g.vec_b = mc_vec_ok<T>(g.B, ldl);
+      launch_gemm<T, true, false, EPI_FUSED>(st, g, 1);
+    }
   }
   GPVAE_CHECK_LAUNCH("gpvae_trsm");
   return 0;

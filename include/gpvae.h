@@ -86,7 +86,8 @@ int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t 
  * reference re-uses jnp.linalg.inv(k_xx + sigma I) for k_px and y (inference.py:450-455).
  * L: [n, ldl] lower factor (strict upper part not referenced); X: [m, ldx], in place:
  *   trans = 1:  X <- X L^-T   (row x -> y with L y = x);     trans = 0:  X <- X L^-1   (L^T y = x);
- * both in turn: X A^-1 with A = L L^T.  Bound: MFMA (m n^2 flop per call).                        */
+ * both in turn: X A^-1 with A = L L^T.  m n^2 flop per call; every element of X has one writer per
+ * launch (no atomics): the same bits on every call.                                               */
 int gpvae_trsm(void *stream, int dtype, int trans, int64_t n, int64_t m, const void *L, int64_t ldl,
                void *X, int64_t ldx);
 
