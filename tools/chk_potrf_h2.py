@@ -32,6 +32,9 @@ for batch in (1, 2, 16):
                 E = ops.randn((256, n), torch.float32, dev, seed=b, stream_id=2)
                 F = ops.draw_h2(P[b], inv[b:b + 1], E2h)
                 Fo = E.double() @ L.T
-                print("   planes b=%d: max|planes/s - L| %.3e  inv %.4e  draw rel err %.3e  finite %s" %
-                      (b, (back - L).abs().max().item(), inv[b].item(),
-                       ((F.double() - Fo).abs().max() / Fo.abs().max()).item(), bool(torch.isfinite(F).all())))
+                Ff = ops.draw(torch.tril(A[b]).contiguous(), E)                                  # f32 MFMA
+                Fb = ops.draw_b3(ops.split_b3(A[b], lower=True), ops.randn_b3((256, n), dev, seed=b, stream_id=2))
+                top = Fo.abs().max()
+                print("   planes b=%d: max|planes/s - L| %.3e  inv %.4e  draw max err / max|F|: fp16x2 %.3e  bf16x3 %.3e  f32 MFMA %.3e" %
+                      (b, (back - L).abs().max().item(), inv[b].item(), ((F.double() - Fo).abs().max() / top).item(),
+                       ((Fb.double() - Fo).abs().max() / top).item(), ((Ff.double() - Fo).abs().max() / top).item()))
