@@ -12,6 +12,7 @@ batched restatement in gp_vae_amd/nuts.py (or the plain HMC of hmc.py) over the 
 """
 import math
 
+import ctypes as C
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -40,8 +41,12 @@ class Potential():
     `gp_regression` methods when they are called with data, i.e. where the reference hands the model
     function to NUTS."""
 
-    def __init__(self, fn, init, unpack):
+    def __init__(self, fn, init, unpack, eval_into=None):
         self.fn, self.init, self.unpack = fn, init, unpack
+        # optional fast path for samplers that call the potential thousands of times per second:
+        # eval_into(q, U_out, g_out, stream_handle) writes into the caller's buffers (q, g_out with unit column
+        # stride), no allocation and no stream look-up per call
+        self.eval_into = eval_into
 
     def __call__(self, q):
         return self.fn(q)
@@ -379,7 +384,21 @@ class VAEInference(Inference):
             z = smp[:, :zd].contiguous()
             return {"z": z, "noise": torch.exp(smp[:, zd]), "f": self.predict(z)}
 
-        return Potential(fn, q0, unpack)
+        eval_into = None
+        if fused:
+            from . import _lib
+            lib, dtc, vp = _lib.load(), ops._dt(y_obs), C.c_void_p
+            p_dec, p_y, p_idx, n_obs = vp(self.dec_flat.data_ptr()), vp(y_obs.data_ptr()), vp(idx.data_ptr()), idx.numel()
+            n_out, h0, h1 = self.n_out, self.h0, self.h1
+
+            def eval_into(q, U_out, g_out, stream_handle):
+                rc = lib.gpvae_vae_potential(stream_handle, dtc, q.shape[0], n_out, h0, h1, zd, p_dec, vp(q.data_ptr()),
+                                             q.stride(0), p_y, p_idx, n_obs, 0.1, vp(U_out.data_ptr()),
+                                             vp(g_out.data_ptr()), g_out.stride(0))
+                if rc:
+                    _lib.check(rc, "gpvae_vae_potential")
+
+        return Potential(fn, q0, unpack, eval_into)
 
     def fit(self, plot=False, rng_key=None, num_prior=1000):
         """Prior and posterior predictive draws y_pred ~ Normal(decoder(z), noise)
