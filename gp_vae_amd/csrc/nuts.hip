@@ -44,6 +44,20 @@ __device__ __forceinline__ bool turning(const T *minv, const T *pa, const T *pb,
   return d1 <= T(0) || d2 <= T(0);
 }
 
+// half kick and drift from the sub-tree's edge: ph, qn (lane j touches element j, j + 64, ... only)
+template <typename T>
+__device__ __forceinline__ void nuts_pre(const gpvae_nuts_buffers &b, int64_t c, int64_t o, int64_t D, int lane,
+                                         const T *minv) {
+  const T es = ((const T *)b.es)[c];
+  const T *pe = (const T *)b.pe + o, *ge = (const T *)b.ge + o, *qe = (const T *)b.qe + o;
+  T *ph = (T *)b.ph + o, *qn = (T *)b.qn + o;
+  for (int64_t j = lane; j < D; j += 64) {
+    const T h = pe[j] - T(0.5) * es * ge[j];
+    ph[j] = h;
+    qn[j] = qe[j] + es * minv[j] * h;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void nuts_kernel(int op, int64_t C, int64_t D, int max_depth, int depth, int leaf,
                                                   int ck_lo, int ck_hi, gpvae_nuts_buffers b) {
@@ -98,14 +112,15 @@ __global__ __launch_bounds__(64) void nuts_kernel(int op, int64_t C, int64_t D, 
       }
     }
   } else if (op == GPVAE_NUTS_PRE) {
-    const T es = S(es);
-    for (int64_t j = lane; j < D; j += 64) {
-      const T ph = V(pe)[j] - T(0.5) * es * V(ge)[j];
-      V(ph)[j] = ph;
-      V(qn)[j] = V(qe)[j] + es * minv[j] * ph;
+    nuts_pre<T>(b, c, o, D, lane, minv);
+  } else if (op == GPVAE_NUTS_POST || op == GPVAE_NUTS_POST_PRE) {
+    // POST_PRE: the leaf's POST and the next leaf's PRE in one launch (PRE reads, lane by lane, what the same
+    // lane's POST wrote: qe, pe, ge).  A chain that is not building skips POST and still runs PRE, as it would
+    // under the separate ops.
+    if (!b.building[c]) {  // wave-uniform
+      if (op == GPVAE_NUTS_POST_PRE) nuts_pre<T>(b, c, o, D, lane, minv);
+      return;
     }
-  } else if (op == GPVAE_NUTS_POST) {
-    if (!b.building[c]) return;  // wave-uniform
     const T es = S(es);
     const T *gn = (const T *)b.gn + c * b.ldg;
     const T Un = ((const T *)b.Un)[c];
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(64) void nuts_kernel(int op, int64_t C, int64_t D, 
         atomicOr(&b.flags[0], 1);
       }
     }
+    if (op == GPVAE_NUTS_POST_PRE) nuts_pre<T>(b, c, o, D, lane, minv);
   } else if (op == GPVAE_NUTS_MERGE) {
     if (!b.active[c]) return;
     const bool ok = !b.sub_stop[c];
@@ -204,7 +220,7 @@ using namespace gpvae;
 extern "C" int gpvae_nuts_op(void *stream, int dtype, int op, int64_t C, int64_t D, int max_depth, int depth, int leaf,
                              int ck_lo, int ck_hi, const gpvae_nuts_buffers *b) {
   GPVAE_REQUIRE(dtype == GPVAE_F32 || dtype == GPVAE_F64, 2, "gpvae_nuts_op: bad dtype %d", dtype);
-  GPVAE_REQUIRE(op >= GPVAE_NUTS_INIT && op <= GPVAE_NUTS_ACCEPT, 3, "gpvae_nuts_op: unknown op %d", op);
+  GPVAE_REQUIRE(op >= GPVAE_NUTS_INIT && op <= GPVAE_NUTS_POST_PRE, 3, "gpvae_nuts_op: unknown op %d", op);
   GPVAE_REQUIRE(C >= 0 && C <= 2147483647, 4, "gpvae_nuts_op: C out of range");
   GPVAE_REQUIRE(D >= 1, 5, "gpvae_nuts_op: D < 1");
   GPVAE_REQUIRE(max_depth >= 1 && max_depth <= 20, 6, "gpvae_nuts_op: max_depth out of range [1,20]");
@@ -221,10 +237,10 @@ extern "C" int gpvae_nuts_op(void *stream, int dtype, int op, int64_t C, int64_t
                     b->ck_s && b->ph && b->qn && b->flags,
                 11, "gpvae_nuts_op: a state buffer is NULL");
   GPVAE_REQUIRE(op != GPVAE_NUTS_INIT || b->z, 11, "gpvae_nuts_op: z is NULL");
-  GPVAE_REQUIRE((op != GPVAE_NUTS_BEGIN && op != GPVAE_NUTS_POST && op != GPVAE_NUTS_MERGE) ||
+  GPVAE_REQUIRE((op != GPVAE_NUTS_BEGIN && op != GPVAE_NUTS_POST && op != GPVAE_NUTS_POST_PRE && op != GPVAE_NUTS_MERGE) ||
                     (b->unif && b->ldu >= 2 * max_depth + ((int64_t)1 << max_depth) - 1),
                 11, "gpvae_nuts_op: unif NULL or ldu < 2 max_depth + 2^max_depth - 1");
-  GPVAE_REQUIRE(op != GPVAE_NUTS_POST || (b->Un && b->gn && b->ldg >= D), 11, "gpvae_nuts_op: Un / gn NULL or ldg < D");
+  GPVAE_REQUIRE((op != GPVAE_NUTS_POST && op != GPVAE_NUTS_POST_PRE) || (b->Un && b->gn && b->ldg >= D), 11, "gpvae_nuts_op: Un / gn NULL or ldg < D");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GPVAE_F32)
     hipLaunchKernelGGL((nuts_kernel<float>), dim3((unsigned)C), dim3(64), 0, st, op, C, D, max_depth, depth, leaf, ck_lo,

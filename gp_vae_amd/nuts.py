@@ -322,7 +322,8 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
             op(1, depth)
             leaves = 1 << depth
             for leaf in range(leaves):
-                op(2, depth)
+                if leaf == 0:
+                    op(2, depth)  # PRE; the later leaves' PRE rides in the previous leaf's POST_PRE launch
                 if eval_into is not None:
                     eval_into(t["qn"], Un_buf, gn_buf, h_stream)
                 else:
@@ -331,7 +332,7 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
                         Un, gn = Un.contiguous(), gn.contiguous()
                     b.Un, b.gn, b.ldg = Un.data_ptr(), gn.data_ptr(), gn.stride(0)
                 lo, hi = _ckpt_range(leaf)
-                op(3, depth, leaf, lo, hi)
+                op(3 if leaf + 1 == leaves else 6, depth, leaf, lo, hi)
                 if leaves >= 8 and (leaf & 3) == 3 and leaf + 1 < leaves and int(t["flags"][0].item()) == 0:
                     break
                 if leaves >= 8 and (leaf & 3) == 3:

@@ -353,6 +353,8 @@ int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int64_t n, int 
  *   GPVAE_NUTS_POST    second half kick, energy error, divergence (> 1000), multinomial choice inside the
  *                      sub-tree (unif[:, 2 max_depth + 2^depth - 1 + leaf]), momentum sum, U-turn checks
  *                      against the checkpoints [ck_lo, ck_hi] of leaf `leaf`; flags[0] |= a chain still builds
+ *   GPVAE_NUTS_POST_PRE  POST of leaf `leaf` followed by PRE of the next leaf in one launch (two launches per
+ *                      leapfrog step instead of three); harmless when the caller then leaves the sub-tree
  *   GPVAE_NUTS_MERGE   biased progressive choice between the tree and the new sub-tree
  *                      (unif[:, max_depth + depth]), edges, weights, U-turn of the whole tree;
  *                      flags[1] |= a chain is still active
@@ -360,7 +362,7 @@ int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int64_t n, int 
  * BEGIN clears flags.  A chain whose tree has stopped rides along untouched, so its numbers do not depend
  * on the other chains of the batch.                                                                   */
 enum { GPVAE_NUTS_INIT = 0, GPVAE_NUTS_BEGIN = 1, GPVAE_NUTS_PRE = 2, GPVAE_NUTS_POST = 3, GPVAE_NUTS_MERGE = 4,
-       GPVAE_NUTS_ACCEPT = 5 };
+       GPVAE_NUTS_ACCEPT = 5, GPVAE_NUTS_POST_PRE = 6 };
 typedef struct gpvae_nuts_buffers {
   void *q, *U, *g;                /* chain state: position, potential, gradient */
   const void *minv, *eps;         /* inverse mass diagonal [C, D], step size [C] */
