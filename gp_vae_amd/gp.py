@@ -79,21 +79,11 @@ def agg_kernel_grid(rng_key, d, m, kernel, var, ls, grid1, grid2=None, jitter=1.
         raise NotImplementedError("agg_kernel_grid is built for exp_kernel2 only")
     if d not in (1, 2):
         raise Warning("Function is only implemented for d=1,2")  # gp.py:117
-    grid1 = _as_device(grid1)
-    n = grid1.shape[0]  # gp.py:99 with the `shape()` typo fixed
+    grid1 = _as_device(grid1)  # n = grid1.shape[0]: gp.py:99 with the `shape()` typo fixed
     if isinstance(rng_key, torch.Tensor) and rng_key.dim() == 3:
-        u = _as_device(rng_key, grid1.dtype)
+        pts = _agg_points(None, d, m, grid1, grid2, u=_as_device(rng_key, grid1.dtype))
     else:
-        gen = torch.Generator(device=grid1.device)
-        gen.manual_seed(_seed_of(rng_key))
-        u = torch.rand((n ** d, m, d), generator=gen, device=grid1.device, dtype=grid1.dtype)
-    if d == 1:
-        pts = u / n + grid1[:, None, None]  # gp.py:107
-    else:
-        g2 = grid1 if grid2 is None else _as_device(grid2, grid1.dtype)
-        uu, vv = torch.meshgrid(grid1, g2, indexing="xy")  # jnp.meshgrid default     gp.py:112
-        org = torch.stack([uu.flatten(), vv.flatten()], dim=1)[:, None, :]  # gp.py:113
-        pts = u / n + org
+        pts = _agg_points(rng_key, d, m, grid1, grid2)
     return ops.gram_agg(pts, var, ls, jitter)
 
 
@@ -168,18 +158,20 @@ class GP():
         return out
 
 
-def _agg_points(rng_key, d, m, grid1, grid2=None):
-    """The cells' Monte-Carlo sample points [n^d, m, d] of agg_kernel_grid (gp.py:98-113)."""
+def _agg_points(rng_key, d, m, grid1, grid2=None, u=None):
+    """The cells' Monte-Carlo sample points [n^d, m, d] of agg_kernel_grid (gp.py:98-113); `u`: ready-made
+    uniforms [n^d, m, d] instead of torch's generator seeded by rng_key."""
     grid1 = _as_device(grid1)
     n = grid1.shape[0]
-    gen = torch.Generator(device=grid1.device)
-    gen.manual_seed(_seed_of(rng_key))
-    u = torch.rand((n ** d, m, d), generator=gen, device=grid1.device, dtype=grid1.dtype)
+    if u is None:
+        gen = torch.Generator(device=grid1.device)
+        gen.manual_seed(_seed_of(rng_key))
+        u = torch.rand((n ** d, m, d), generator=gen, device=grid1.device, dtype=grid1.dtype)
     if d == 1:
-        return u / n + grid1[:, None, None]
+        return u / n + grid1[:, None, None]  # gp.py:107
     g2 = grid1 if grid2 is None else _as_device(grid2, grid1.dtype)
-    uu, vv = torch.meshgrid(grid1, g2, indexing="xy")
-    return u / n + torch.stack([uu.flatten(), vv.flatten()], dim=1)[:, None, :]
+    uu, vv = torch.meshgrid(grid1, g2, indexing="xy")  # jnp.meshgrid default     gp.py:112
+    return u / n + torch.stack([uu.flatten(), vv.flatten()], dim=1)[:, None, :]  # gp.py:113
 
 
 class PoiGP(GP):
