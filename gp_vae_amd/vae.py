@@ -602,8 +602,9 @@ class VAE():
     obs_sigma = 0.1  # vae.py:117
 
     def __init__(self, gp, hidden_dims, z_dim, out_dim, batch_size, learning_rate, num_epochs,
-                 num_train, num_test, x, seed=0, dtype=torch.float32, pipelined=True):
+                 num_train, num_test, x, seed=0, dtype=torch.float32, pipelined=True, mfma="auto"):
         self.gp = gp
+        self.mfma = mfma  # StepEngine's matrix-pipe route for float32 draws: "auto" | "f32" | "bf16x3" | "f16x2"
         assert len(hidden_dims) == 2  # vae.py:55
         self.hidden_dims = hidden_dims
         self.z_dim = z_dim
@@ -702,7 +703,7 @@ class VAE():
             h0, h1 = self.hidden_dims
             self.engine = StepEngine(self.x, self.gp.jitter, (h0, h1, self.z_dim), self.batch_size,
                                      self.learning_rate, self.dtype, self.seed, obs_sigma=self.obs_sigma,
-                                     kernel=self.gp.kernel)
+                                     kernel=self.gp.kernel, mfma=self.mfma)
         return self.engine
 
     def _ensure_svi(self):
