@@ -139,6 +139,17 @@ ffi::Error HyperSample(hipStream_t s, int64_t seed, int64_t stream_id, int64_t f
                                    var->untyped_data(), sigma->untyped_data()));
 }
 
+// ---- f4: the LGCP observation of PoiGP.sample: rate = exp(f), y ~ Poisson(rate) (gp.py:249-250) ----------
+ffi::Error PoissonExp(hipStream_t s, int64_t seed, int64_t stream_id, int64_t first_index, ffi::AnyBuffer f,
+                      ffi::Result<ffi::AnyBuffer> rate, ffi::Result<ffi::AnyBuffer> y) {
+  ffi::Error err = ffi::Error::Success();
+  const int dt = DType(f.element_type(), &err);
+  if (err.failure()) return err;
+  if (y->element_type() != ffi::DataType::S32) return ffi::Error::InvalidArgument("gpvae_poisson_exp: y must be int32");
+  return Status(gpvae_poisson_exp(s, dt, (int64_t)f.element_count(), (uint64_t)seed, (uint64_t)stream_id, first_index,
+                                  f.untyped_data(), rate->untyped_data(), (int32_t *)y->untyped_data()));
+}
+
 // ---- a9 / f2: kriging (inference.py:427-460; the vmap of 511-521 when var / ls / sigma are vectors) -----
 // x_obs [n_obs, d], x_test [n_test, d], y_obs [n_obs], var, ls, sigma [batch], xi [batch, n_test]
 //   -> mean, sample, var_out [batch, n_test], info [batch]
@@ -306,6 +317,9 @@ XLA_FFI_DEFINE_HANDLER_SYMBOL(gpvae_hyper_sample_ffi, HyperSample,
     ffi::Ffi::Bind().Ctx<Stream>().Attr<int64_t>("seed").Attr<int64_t>("stream_id").Attr<int64_t>("first_index")
         .Attr<int32_t>("ls_prior").Attr<double>("ls_a").Attr<double>("ls_b").Attr<double>("var_scale")
         .Attr<double>("sigma_scale").Ret<RET>().Ret<RET>().Ret<RET>());
+XLA_FFI_DEFINE_HANDLER_SYMBOL(gpvae_poisson_exp_ffi, PoissonExp,
+    ffi::Ffi::Bind().Ctx<Stream>().Attr<int64_t>("seed").Attr<int64_t>("stream_id").Attr<int64_t>("first_index")
+        .Arg<ARG>().Ret<RET>().Ret<RET>());
 XLA_FFI_DEFINE_HANDLER_SYMBOL(gpvae_krig_predict_ffi, KrigPredict,
     ffi::Ffi::Bind().Ctx<Stream>().Ctx<ffi::ScratchAllocator>().Arg<ARG>().Arg<ARG>().Arg<ARG>().Arg<ARG>().Arg<ARG>()
         .Arg<ARG>().Arg<ARG>().Attr<double>("jitter").Ret<RET>().Ret<RET>().Ret<RET>().Ret<ffi::Buffer<ffi::S32>>());

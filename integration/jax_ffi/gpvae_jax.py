@@ -23,7 +23,7 @@ import numpy as np
 
 _TARGETS = ["gram_se", "gram_agg", "potrf", "draw", "draw_batched", "randn", "hyper_sample", "krig_predict",
             "mvn_logp", "gp_potential", "vae_elbo", "encoder_fwd", "adam", "decoder_fwd", "decoder_vjp",
-            "vae_potential"]
+            "vae_potential", "poisson_exp"]
 
 
 def register(path):
@@ -144,6 +144,12 @@ def vae_potential(dec_flat, q, y_obs, obs_idx, n, dims, noise_scale=0.1):
     return jax.ffi.ffi_call("gpvae_vae_potential", (_sds((q.shape[0],), q.dtype), _sds(q.shape, q.dtype)))(
         dec_flat, q, y_obs, jnp.asarray(obs_idx, jnp.int64), n=np.int64(n), h0=np.int32(h0), h1=np.int32(h1),
         noise_scale=np.float64(noise_scale))
+
+
+def lgcp_observation(f, seed=0, stream_id=0, first_index=0):
+    """(rate, y): rate = exp(f), y ~ Poisson(rate) int32 — the last two lines of PoiGP.sample (gp.py:249-250)."""
+    return jax.ffi.ffi_call("gpvae_poisson_exp", (_sds(f.shape, f.dtype), _sds(f.shape, jnp.int32)))(
+        f, seed=np.int64(seed), stream_id=np.int64(stream_id), first_index=np.int64(first_index))
 
 
 def potential_fn(call):
