@@ -55,7 +55,9 @@ __device__ __forceinline__ void split2_f16(float v, _Float16 &h, _Float16 &l) {
 __device__ __forceinline__ float h2_scale(float bound) {  // 2^e with bound * 2^e in (2^13, 2^14]
   int ex;
   (void)frexpf(bound, &ex);  // bound = m 2^ex, m in [0.5, 1)
-  return ldexpf(1.0f, 14 - ex);
+  int e = 14 - ex;           // |e| <= 62: the trailing update squares the scale, and 2^(2e) must stay a float
+  e = e > 62 ? 62 : (e < -62 ? -62 : e);
+  return ldexpf(1.0f, e);
 }
 
 // WFM_ = 4: the 256 x 128 tile described above.  WFM_ = 2: a 128 x 128 tile (wave tiles 64 x 64, 99.8 KB of
