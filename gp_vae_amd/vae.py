@@ -255,10 +255,11 @@ class StepEngine():
     The factors of the next `group` steps are independent of the network, so they are built as ONE
     batched Gram + batched Cholesky launch sequence on a side stream (throughput mode of the panel
     sweep instead of `group` latency-bound single factorisations), one group ahead of the
-    draw/ELBO/Adam chain; 2 x group factor slots live in HBM (group=8, n=4096, f32: 1 GiB)."""
+    draw/ELBO/Adam chain; 2 x group factor slots live in HBM (group=16, n=4096, f32: 2 GiB; the default
+    group is 16, less when a slot would exceed 8 GiB)."""
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
-                 hyper_sampler=draw_hyper, overlap=True, group=8, kernel=exp_kernel2, mfma="auto",
+                 hyper_sampler=draw_hyper, overlap=True, group=None, kernel=exp_kernel2, mfma="auto",
                  first_group=None):
         self.first_group = first_group  # int or sequence: sizes of the first factor groups; None: default_ramp
         self.default_ramp = ()
@@ -291,8 +292,12 @@ class StepEngine():
                           "before the first HIP call, or the factor stream no longer overlaps the training steps")
         dev = self.x.device
         n, B = self.n, self.B
-        self.G = max(1, int(group))
         self.ld = (n + 3) // 4 * 4  # 16-byte aligned rows for the vector loads
+        if group is None:
+            # a factorisation call carries the latency of its dependent panel launches whatever its batch, so
+            # full groups of 16 measured best at C3; larger problems take what 8 GiB per slot holds
+            group = max(2, min(16, (8 << 30) // max(1, n * self.ld * self.x.element_size())))
+        self.G = max(1, int(group))
         G = self.G
         self.Kbuf = [torch.empty((G, n, self.ld), dtype=dtype, device=dev) for _ in range(2)]
         self.hyper_dev = [torch.empty((3, G), dtype=dtype, device=dev) for _ in range(2)]  # var|ls|sigma
