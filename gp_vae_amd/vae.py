@@ -249,6 +249,21 @@ def load_decoder_params(path, dtype=None, device=None):
     return [(t[0], t[1]), (), (t[2], t[3]), (), (t[4], t[5])]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """The factor stream and the normals stream of every StepEngine on `dev`: created once per process.
+    HIP deals streams to GPU_MAX_HW_QUEUES hardware queues in creation order, and a side stream that lands on the
+    main stream's queue serialises behind it: with a fresh pair per engine every SECOND engine of a process ran
+    the C3 step in 0.90-0.96 instead of 0.81 ms (tools/soak_c3.py; 4 queues, the boxes' setting).  Engines of one
+    process therefore share the first pair, whose placement is the one bench.py measures."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _SIDE_STREAMS[key]
+
+
 class StepEngine():
     """One training/evaluation step = gram -> potrf -> draw -> ELBO (-> all-reduce -> Adam).
 
@@ -340,8 +355,7 @@ class StepEngine():
         self.loss_sum = torch.zeros(1, dtype=dtype, device=dev)
         self.work = ops.VaeWorkspace(B, n, self.h0, self.h1, self.z, dtype, dev)
         self.overlap = overlap
-        self.s_gp = torch.cuda.Stream(device=dev) if overlap else None
-        self.s_rng = torch.cuda.Stream(device=dev) if overlap else None
+        self.s_gp, self.s_rng = _side_streams(dev) if overlap else (None, None)
         self.ev_drawn, self.ev_rng = torch.cuda.Event(), torch.cuda.Event()
         self._rng_pending = False
         self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # factors of group slot s are ready
