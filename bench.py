@@ -151,14 +151,14 @@ def _event_time(f, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def extras(ops, x, dev):
+def extras(ops, x, dev, out=None):
     """Bounded side measurements under the driver's clock (about 5 s in all, rank 0, N = 1):
     the Gram builder's achieved HBM write rate (its bound), and one number each for
     the other BASELINE.json configurations C2, C4 and C5.  Their parity is the tests' business."""
     import math
     from gp_vae_amd.vae import StepEngine, SVIState, init_params, decoder_list_from_flat
     from gp_vae_amd.inference import VAEInference
-    out = {}
+    out = {} if out is None else out  # filled as it goes: what was measured before a failure stays in the line
     # a1: Gram build at the training factor group's shape (16 x 4096 x 4096), f32 and f64
     for dt, tag in ((torch.float32, "gram"), (torch.float64, "gram_f64")):
         xx = x.to(dt)
@@ -486,7 +486,7 @@ def main():
         # the side measurements must not cost the headline its line: a failure in one of them is reported, not raised
         if world == 1 and not args.no_extras:
             try:
-                out.update(extras(ops, x, dev))
+                extras(ops, x, dev, out)
             except Exception as e:  # noqa: BLE001
                 out["extras_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
