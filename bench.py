@@ -331,6 +331,10 @@ def main():
     ap.add_argument("--first-group", type=str, default="", help="sizes of the first factor groups, e.g. 4,4,8 (a ramp; then full groups); empty = the engine's default")
     ap.add_argument("--mfma", choices=["auto", "f32", "bf16x3", "f16x2"], default="auto",
                     help="matrix pipe of the float32 draws: bf16x3 (default where shapes allow) or the f32 MFMA")
+    ap.add_argument("--hyper", choices=["host", "device"], default="device",
+                    help="where the step's (ls, var, sigma) are drawn from the reference's priors (vae.py:157-159): "
+                         "gpvae_hyper_sample on the factor stream (default), or host NumPy with 3 floats uploaded per "
+                         "step (measured 3 %% slower at 1000 steps, 1-2 %% at 20: DESIGN.md §7)")
     ap.add_argument("--force-collective", action="store_true",
                     help="single GPU: create a one-rank RCCL group and run the per-step all-reduce anyway")
     ap.add_argument("--dry-run", action="store_true",
@@ -365,7 +369,7 @@ def main():
     dev = torch.device("cuda", local)
     x = torch.tensor(grid_points(), device=dev)
     eng = StepEngine(x, JITTER, DIMS, B, LR, dtype=torch.float32, seed=1, overlap=not args.no_overlap,
-                     hyper_sampler=bench_hyper, group=args.group, mfma=args.mfma,
+                     hyper_sampler=bench_hyper if args.hyper == "host" else "device", group=args.group, mfma=args.mfma,
                      first_group=[int(v) for v in args.first_group.split(",")] if args.first_group else None)
     state = SVIState(init_params(N, *DIMS, 1, torch.float32, dev))
 
@@ -470,6 +474,7 @@ def main():
                        "n": N, "draws_per_step_per_gpu": B, "hidden_dims": list(DIMS[:2]),
                        "z_dim": DIMS[2], "parallelism": "dp%d" % world,
                        "draw_mfma": "bf16x3" if eng.b3 else ("f16x2" if getattr(eng, "h2", False) else "f32"),
+                       "hyper_priors_drawn_on": args.hyper,
                        "factor_stream_overlap": not args.no_overlap, "factor_group": args.group,
                        "forced_single_rank_collective": bool(args.force_collective)},
             "roofline": roof,
