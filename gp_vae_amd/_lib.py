@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpvae_hip.so")
 
 F32, F64 = 0, 1
+ABI_VERSION = 2  # include/gpvae.h GPVAE_ABI_VERSION
 POTRF_ZERO_UPPER, POTRF_NAN_ON_FAIL = 1, 2
 
 
@@ -93,8 +94,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gpvae_abi_version() != 1:
-        raise GpvaeError("libgpvae_hip.so ABI version mismatch")
+    if lib.gpvae_abi_version() != ABI_VERSION:
+        raise GpvaeError("libgpvae_hip.so reports ABI version %d, this binding was written for %d (include/gpvae.h: "
+                         "GPVAE_ABI_VERSION) — rebuild with `make -C gp_vae_amd/csrc`" % (lib.gpvae_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

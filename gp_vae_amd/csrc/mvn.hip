@@ -217,11 +217,24 @@ __global__ __launch_bounds__(256) void gp_finish_kernel(int64_t n, int64_t n_lik
   for (int64_t i = tid; i < n; i += 256) db[i] = -gf[b * n + i];  // dU/df = -dlogMVN/df (+ likelihood below)
   __syncthreads();
   T sq = T(0);
-  for (int64_t j = tid; j < n_lik; j += 256) {
-    const int64_t i = lik_idx ? lik_idx[j] : j;
-    const T r = (y_lik[j] - qb[i]) * isig;
-    sq += r * r;
-    db[i] -= r * isig;  // indices are distinct: no two threads touch one entry
+  if (lik_idx == nullptr) {
+    for (int64_t j = tid; j < n_lik; j += 256) {
+      const T r = (y_lik[j] - qb[j]) * isig;
+      sq += r * r;
+      db[j] -= r * isig;
+    }
+  } else {
+    // f[lik_idx] may name a point more than once (the reference's gather counts it once per occurrence):
+    // entry i of dU belongs to thread i % 256, which adds its observations in index order — one writer per
+    // entry, the same bits on every call.  An index outside [0, n) contributes nothing (memory safety only:
+    // the host wrappers reject such index sets).
+    for (int64_t j = 0; j < n_lik; ++j) {
+      const int64_t i = lik_idx[j];
+      if ((uint64_t)i >= (uint64_t)n) continue;
+      const T r = (y_lik[j] - qb[i]) * isig;
+      if ((j & 255) == tid) sq += r * r;
+      if ((i & 255) == tid) db[i] -= r * isig;
+    }
   }
   sq = wave_sum<T>(sq);
   if ((tid & 63) == 0) red[tid >> 6] = sq;

@@ -998,9 +998,15 @@ __global__ __launch_bounds__(NTHREADS) void vae_potential_kernel(
   const int rows = (int)((chains - c0 < RB) ? chains - c0 : RB);
   const T *V3 = dec_params + nmid, *c3 = V3 + (int64_t)h0 * n;
   for (int i = tid; i < nmid; i += NTHREADS) w[i] = dec_params[i];
-  for (int i = tid; i < h0 * n_obs; i += NTHREADS) V3g[i] = V3[(int64_t)(i / n_obs) * n + obs_idx[i % n_obs]];
+  // gather of the observed columns (a column named twice is gathered twice: f[obs_idx] counts it twice, as the
+  // reference's does).  An index outside [0, n) is clamped — memory safety only, the host wrappers reject it.
+  auto col = [&](int j) -> int64_t {
+    const int64_t c = obs_idx[j];
+    return c < 0 ? 0 : (c >= n ? (int64_t)n - 1 : c);
+  };
+  for (int i = tid; i < h0 * n_obs; i += NTHREADS) V3g[i] = V3[(int64_t)(i / n_obs) * n + col(i % n_obs)];
   for (int i = tid; i < n_obs; i += NTHREADS) {
-    c3g[i] = c3[obs_idx[i]];
+    c3g[i] = c3[col(i)];
     yo[i] = y_obs[i];
   }
   for (int i = tid; i < RB * z; i += NTHREADS) Zb[i] = (i / z < rows) ? q[(c0 + i / z) * ldq + i % z] : T(0);
@@ -1262,11 +1268,13 @@ extern "C" int gpvae_vae_potential(void *stream, int dtype, int64_t chains, int6
 // ---- the one entry point that takes no workspace and allocates nothing ------------------------------
 // For callers that cannot allocate or carry a workspace: code under HIP graph capture, tight MCMC /
 // serving loops, harnesses that forbid hipMalloc.  Same kernels as gpvae_decoder_vjp; the scratch
-// (D1 | D2 | dD2, chains * (h1 + 2 h0) elements) is a file-scope device array, one copy per GPU for
-// the life of the process.  In host code the array's NAME is only a stand-in: its device address is
-// looked up once per device with hipGetSymbolAddress and only that pointer is handed to kernels and
-// memsets.  Every call on a GPU shares that GPU's array (calls that overlap on one GPU race); what
-// must start from zero (dD2, the split-K accumulator) is cleared by the call itself.
+// (D1 | D2 | dD2 | ns k-slice slabs of dD2: chains * (h1 + (2 + ns) h0) elements, exactly
+// gpvae_decoder_workspace_bytes — run_decoder's layout) is a file-scope device array, one copy per GPU
+// for the life of the process.  In host code the array's NAME is only a stand-in: its device address is
+// looked up once per device with hipGetSymbolAddress and only that pointer is handed to kernels.
+// Every call on a GPU shares that GPU's array (calls that overlap on one GPU race).  Nothing needs
+// clearing: each k-slice of the n-sized product STORES its slab and the mid-layer kernel adds the slabs
+// in slice order (no accumulator that must start from zero, no memset).
 static_assert(GPVAE_STATIC_SCRATCH_BYTES == (4 << 20), "include/gpvae.h states 4 MiB per GPU");
 static __device__ __align__(256) unsigned char scratch[GPVAE_STATIC_SCRATCH_BYTES];
 

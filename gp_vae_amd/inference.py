@@ -26,11 +26,18 @@ from .parallel import dist_info, shard
 from .vae import decoder_flat_from_list
 
 
-def _index(idx, device):
-    """Index array (list / numpy / tensor on any device) as a long tensor on `device`."""
+def _index(idx, device, n=None, what="obs_idx"):
+    """Index array (list / numpy / tensor on any device) as a long tensor on `device`; with n, every entry must
+    lie in [0, n) (checked once, here, where the index set enters — the kernels that gather and scatter through
+    it do not re-check per call).  Repeats are legal, as in the reference's f[obs_idx]."""
     if isinstance(idx, torch.Tensor):
-        return idx.to(device=device, dtype=torch.long)
-    return torch.as_tensor(np.asarray(idx), dtype=torch.long, device=device)
+        t = idx.to(device=device, dtype=torch.long)
+    else:
+        t = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=device)
+    t = t.reshape(-1).contiguous()
+    if n is not None:
+        ops.check_index(t, n, what)
+    return t
 
 
 class Potential():
@@ -60,7 +67,7 @@ class Inference():
         self.d = d
         self.x = _as_device(x, dtype)
         self.y = _as_device(y, dtype)
-        self.obs_idx = _index(obs_idx, self.x.device)
+        self.obs_idx = _index(obs_idx, self.x.device, self.x.shape[0])
         self.mcmc_args = mcmc_args
         self.seed = seed
         self.ground_truth = ground_truth
@@ -189,7 +196,7 @@ class GPInference(Inference):
             d_f = gf + r / sig[:, None]
         else:
             d_f = gf.clone()
-            d_f[:, lik_idx] += r / sig[:, None]
+            d_f.index_add_(1, lik_idx, r / sig[:, None])  # repeats in lik_idx accumulate
         d_uv = -uv / s0 ** 2 + gv * var
         d_ul = -4.0 + 1.0 / ls + gl * ls
         d_us = 1.0 - (sig / s0) ** 2 + sq - m
@@ -220,7 +227,8 @@ class GPInference(Inference):
         y_lik = y_lik.contiguous()
 
         def fn(q):  # one library call per evaluation (gpvae_gp_potential)
-            U, dU, info = ops.gp_potential(x_pts, q if q.stride(1) == 1 else q.contiguous(), y_lik, lik_idx, 1.0e-5)
+            U, dU, info = ops.gp_potential(x_pts, q if q.stride(1) == 1 else q.contiguous(), y_lik, lik_idx, 1.0e-5,
+                                           checked=True)
             self.last_info = info
             return U, dU
 
@@ -265,7 +273,7 @@ class GPInference(Inference):
         what Predictive(self.regression, num_samples | posterior_samples)(rng_key) returns."""
         if y is None:
             return self._predictive_draws(self.x, rng_key, num_samples or 1, posterior_samples)
-        idx = self.obs_idx if obs_idx is None else _index(obs_idx, self.x.device)
+        idx = self.obs_idx if obs_idx is None else _index(obs_idx, self.x.device, self.x.shape[0])
         yy = _as_device(y, self.dtype)
         return self._latent_gp_model(self.x, yy[idx], idx)
 
@@ -343,6 +351,7 @@ class VAEInference(Inference):
         (V1, _), _, (V2, _), _, (V3, _) = decoder_params
         self.h1, self.h0, self.n_out = V1.shape[1], V2.shape[1], V3.shape[1]
         self.dec_flat = decoder_flat_from_list(decoder_params, self.dtype)
+        ops.check_index(self.obs_idx, self.n_out, "obs_idx (decoder outputs)")
 
     def regression(self, y=None, obs_idx=None, rng_key=None, num_samples=None, posterior_samples=None):
         """Regression model with the decoder as prior (inference.py:235-254).
@@ -364,7 +373,7 @@ class VAEInference(Inference):
             f = self.predict(z)
             y_pred = f + noise[:, None] * ops.randn(tuple(f.shape), dt, dev, seed=seed, stream_id=base | 7)
             return {"noise": noise, "z": z, "f": f, "y_pred": y_pred}
-        idx = self.obs_idx if obs_idx is None else _index(obs_idx, dev)
+        idx = self.obs_idx if obs_idx is None else _index(obs_idx, dev, self.n_out)
         y_obs = _as_device(y, dt)[idx]
         q0 = torch.zeros(zd + 1, dtype=dt, device=dev)
         q0[zd] = math.log(0.0674)  # median of HalfNormal(0.1)
@@ -376,7 +385,7 @@ class VAEInference(Inference):
         def fn(q):
             if fused:  # one launch per evaluation (gpvae_vae_potential)
                 return ops.vae_potential(self.dec_flat, q if q.stride(1) == 1 else q.contiguous(), y_obs, idx,
-                                         self.n_out, self.h0, self.h1)
+                                         self.n_out, self.h0, self.h1, checked=True)
             U, dz, du = self._potential(q[:, :zd], q[:, zd], y_obs, idx)
             return U, torch.cat([dz, du[:, None]], 1)
 
@@ -445,7 +454,7 @@ class VAEInference(Inference):
         log_ps = math.log(2.0) - half_log_2pi - math.log(s0) - 0.5 * (sigma / s0) ** 2 + u
         U = -(log_lik + log_pz + log_ps)
         dF = torch.zeros_like(f)
-        dF[:, obs_idx] = r / (sigma ** 2)[:, None]
+        dF.index_add_(1, obs_idx, r / (sigma ** 2)[:, None])  # repeats in obs_idx accumulate
         dz = z + ops.decoder_vjp(self.dec_flat, z, dF, self.h0, self.h1)
         du = (sigma / s0) ** 2 - 1.0 + n_obs - sq / sigma ** 2
         return U, dz, du

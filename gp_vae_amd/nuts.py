@@ -287,7 +287,8 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
 
     # the stream the caller is on when the run starts carries every launch of the run (looking the current
     # stream up per call cost more host time than the launch itself: 62 k look-ups in a 200-iteration run)
-    h_stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run_stream = torch.cuda.current_stream(dev)
+    h_stream = C.c_void_p(run_stream.cuda_stream)
     nuts_op = lib.gpvae_nuts_op
 
     def op(code, depth=0, leaf=0, lo=0, hi=0):
@@ -306,6 +307,12 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
     n_div = torch.zeros((), dtype=torch.long, device=dev)
     n_leap = torch.zeros(Cn, dtype=dt, device=dev)
     for it in range(num_warmup + num_samples):
+        # the torch-side operations of an iteration (noise and step-size copies, flag polls and clears, adapter
+        # updates) must be ordered with the gpvae_nuts_op launches, which go to the stream captured above: one
+        # look-up per iteration makes sure a potential or noise_fn has not left another stream current
+        if torch.cuda.current_stream(dev).cuda_stream != run_stream.cuda_stream:
+            raise _lib.GpvaeError("nuts_device: the current HIP stream changed during the run (potential_and_grad / "
+                                  "noise_fn must restore the stream they were called on)")
         warm = it < num_warmup
         t["eps"].copy_(ad.step_size(warm))
         minv = ad.minv.contiguous()

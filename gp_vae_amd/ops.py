@@ -509,9 +509,23 @@ def mvn_logp(x, f, var, ls, jitter=1.0e-5, grad=True):
     return logp, gf, gv, gl, info
 
 
-def gp_potential(x, q, y_lik, lik_idx=None, jitter=1.0e-5):
+def check_index(idx, n, what="index"):
+    """Raise unless every entry of the int64 device tensor idx lies in [0, n).  One host synchronisation: call it
+    where an index set is BUILT (Inference.__init__ / regression), not per potential evaluation.  Repeated
+    entries are legal: f[obs_idx] counts such a point once per occurrence, as the reference's gather does."""
+    if idx.dtype != torch.long:
+        raise GpvaeError("%s must be an int64 tensor" % what)
+    if idx.numel() and (int(idx.min().item()) < 0 or int(idx.max().item()) >= int(n)):
+        raise GpvaeError("%s out of range: entries must lie in [0, %d) (got min %d, max %d)"
+                         % (what, int(n), int(idx.min().item()), int(idx.max().item())))
+    return idx
+
+
+def gp_potential(x, q, y_lik, lik_idx=None, jitter=1.0e-5, checked=False):
     """(U [chains], dU/dq [chains, n+3], info) of the latent-f GP regression model for rows
-    q = (f [n], log var, log ls, log sigma): gpvae_gp_potential (inference.py:359-424)."""
+    q = (f [n], log var, log ls, log sigma): gpvae_gp_potential (inference.py:359-424).
+    lik_idx (int64, repeats allowed) is range-checked here unless the caller did so already (checked=True:
+    samplers call this thousands of times with one index set)."""
     _dev(x, q, y_lik, lik_idx)
     x = _points(x)
     n, d = x.shape
@@ -524,6 +538,8 @@ def gp_potential(x, q, y_lik, lik_idx=None, jitter=1.0e-5):
         lik_idx = lik_idx.contiguous()
         if lik_idx.dtype != torch.long or lik_idx.numel() != n_lik:
             raise GpvaeError("gp_potential: lik_idx must be int64 with one entry per observation")
+        if not checked:
+            check_index(lik_idx, n, "gp_potential: lik_idx")
     lib = _lib.load()
     work = torch.empty(max(16, lib.gpvae_gp_potential_workspace_bytes(_dt(x), n, chains)), dtype=torch.uint8, device=x.device)
     U = torch.empty(chains, dtype=x.dtype, device=x.device)
@@ -634,12 +650,17 @@ def vae_potential_supported(dtype, h0, h1, z, n_obs):
     return bool(_lib.load().gpvae_vae_potential_supported(_DT[dtype], h0, h1, z, int(n_obs)))
 
 
-def vae_potential(dec_params, q, y_obs, obs_idx, n, h0, h1, noise_scale=0.1):
+def vae_potential(dec_params, q, y_obs, obs_idx, n, h0, h1, noise_scale=0.1, checked=False):
     """(U [chains], dU/dq [chains, z+1]) of VAEInference.regression for q = (z, log noise) rows: one launch
-    (gpvae_vae_potential).  obs_idx: int64 device tensor."""
+    (gpvae_vae_potential).  obs_idx: int64 device tensor (repeats allowed), range-checked here unless
+    checked=True."""
     _dev(dec_params, q, y_obs, obs_idx)
     if q.stride(1) != 1 or obs_idx.dtype != torch.long or not obs_idx.is_contiguous() or not y_obs.is_contiguous():
         raise GpvaeError("vae_potential: q needs unit column stride; obs_idx int64 contiguous; y_obs contiguous")
+    if y_obs.numel() != obs_idx.numel():
+        raise GpvaeError("vae_potential: one observation per entry of obs_idx")
+    if not checked:
+        check_index(obs_idx, n, "vae_potential: obs_idx")
     chains, z = q.shape[0], q.shape[1] - 1
     U = torch.empty(chains, dtype=q.dtype, device=q.device)
     dU = torch.empty((chains, z + 1), dtype=q.dtype, device=q.device)

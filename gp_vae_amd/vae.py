@@ -621,9 +621,16 @@ class VAE():
     obs_sigma = 0.1  # vae.py:117
 
     def __init__(self, gp, hidden_dims, z_dim, out_dim, batch_size, learning_rate, num_epochs,
-                 num_train, num_test, x, seed=0, dtype=torch.float32, pipelined=True, mfma="auto"):
+                 num_train, num_test, x, seed=0, dtype=torch.float32, pipelined=True, mfma="auto",
+                 hyper_sampler="device"):
         self.gp = gp
         self.mfma = mfma  # StepEngine's matrix-pipe route for float32 draws: "auto" | "f32" | "bf16x3" | "f16x2"
+        # where each step's (ls, var, sigma) come from (vae.py:157-159 priors): "device" — gpvae_hyper_sample on the
+        # factor stream, the configuration bench.py times — or a callable rng -> (ls, var, sigma) run on the host
+        # (gp.draw_hyper: NumPy's generators).  The pipelined engine and the literal loop draw the same values.
+        if isinstance(hyper_sampler, str) and hyper_sampler != "device":
+            raise ValueError("hyper_sampler: a callable rng -> (ls, var, sigma) or 'device'")
+        self.hyper_sampler = hyper_sampler
         assert len(hidden_dims) == 2  # vae.py:55
         self.hidden_dims = hidden_dims
         self.z_dim = z_dim
@@ -722,7 +729,7 @@ class VAE():
             h0, h1 = self.hidden_dims
             self.engine = StepEngine(self.x, self.gp.jitter, (h0, h1, self.z_dim), self.batch_size,
                                      self.learning_rate, self.dtype, self.seed, obs_sigma=self.obs_sigma,
-                                     kernel=self.gp.kernel, mfma=self.mfma)
+                                     kernel=self.gp.kernel, mfma=self.mfma, hyper_sampler=self.hyper_sampler)
         return self.engine
 
     def _ensure_svi(self):
@@ -739,7 +746,12 @@ class VAE():
         rank, _ = dist_info()
         total = torch.zeros(1, dtype=self.dtype, device=self.x.device)
         for key in keys:
-            ls, var, sigma = draw_hyper(step_rng(self.seed, rank, key))
+            if isinstance(self.hyper_sampler, str):  # "device": sample key[-1] of the (rank, epoch key) Philox stream
+                ls, var, sigma = (float(t.item()) for t in ops.hyper_sample(
+                    1, self.dtype, self.x.device, seed=self.seed, stream_id=philox_stream_id(rank, (key[0], 0), 5),
+                    first_index=key[-1]))
+            else:
+                ls, var, sigma = self.hyper_sampler(step_rng(self.seed, rank, key))
             pk = PhiloxKey(self.seed, philox_stream_id(rank, key, 0))
             batch = self.gp_predictive(pk, self.x, ls=float(ls), var=float(var), sigma=float(sigma))
             if train:

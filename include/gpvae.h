@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define GPVAE_ABI_VERSION 1
+/* 2: workspace contents changed (round 2): gpvae_potrf_workspace_bytes also covers the bf16 planes of the
+ * current 256-column panel (float32, n % 256 == 0, n >= 512, m_extra == 0: trailing updates on the bf16 matrix
+ * pipe), decoder / mvn workspaces hold per-slice slabs instead of atomically accumulated buffers.  A caller must
+ * size every workspace with the *_workspace_bytes query of the library it runs against. */
+#define GPVAE_ABI_VERSION 2
 
 enum { GPVAE_F32 = 0, GPVAE_F64 = 1 };
 
@@ -73,8 +77,13 @@ int gpvae_gram_agg(void *stream, int dtype, int d, int64_t n_cells, int m, const
  * The strict upper triangle is not referenced, except that it is cleared inside the 64x64
  * diagonal blocks (and everywhere with GPVAE_POTRF_ZERO_UPPER).
  * info[b] (int32): 0 = ok, j>0 = leading minor j not positive definite (LAPACK potrf).
- * work: gpvae_potrf_workspace_bytes() bytes, 16-byte aligned (factored diagonal blocks are parked
- * there until the last launch, so late workgroups of a panel launch never see a half-updated A).   */
+ * work: gpvae_potrf_workspace_bytes() bytes, 16-byte aligned.  Contents: the factored diagonal blocks,
+ * parked there until the last launch (late workgroups of a panel launch never see a half-updated A),
+ * and — float32 with n % 256 == 0, n >= 512 and m_extra == 0 — behind them batch * 3 * n * 256 bf16
+ * values: the current 256-column panel as three bf16 planes (exact 8+8+8-bit split of every float).
+ * On that route the trailing updates C -= P P^T run on the bf16 matrix pipe from those planes (six
+ * piece products per float product, f32 accumulation: float32-accurate, csrc/b3.hpp); every other
+ * shape and dtype uses the f32 / f64 MFMA.  Always size `work` with the query below.                 */
 int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch);
 int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
                 int64_t strideA, int64_t m_extra, void *X, int64_t ldx, int64_t strideX,

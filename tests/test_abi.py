@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gpvae_abi_version() == 1
+    assert lib.gpvae_abi_version() == 2
 
 
 def test_no_torch_types_in_the_abi():

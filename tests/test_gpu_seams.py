@@ -164,18 +164,27 @@ def test_literal_loop_equals_pipelined_engine():
     from gp_vae_amd.vae import VAE
     n = 96
     x = np.arange(0, 1, 1 / n)
-    res = []
-    for pipelined in (True, False):
-        gp = GP(kernel=exp_kernel2, jitter=1e-3, d=1)
-        vae = VAE(gp, [12, 9], 4, n, 40, 1e-3, 1, 7, 3, x, seed=3, dtype=torch.float64, pipelined=pipelined)
-        st = vae.svi_init()
-        st.params.mul_(5)
-        loss, st = vae.epoch_train(123, st)
-        res.append((loss.item(), st.params.clone(), vae.eval_test(9, st), st.t))
-    assert res[0][3] == res[1][3] == 7
-    assert abs(res[0][0] - res[1][0]) < 1e-10 * abs(res[0][0])
-    assert rel(res[0][1], res[1][1].cpu().numpy()) < 1e-10
-    assert abs(res[0][2] - res[1][2]) < 1e-10 * abs(res[0][2])
+    from gp_vae_amd.gp import draw_hyper
+    losses = {}
+    for sampler in ("device", draw_hyper):  # gpvae_hyper_sample (VAE's default, what bench.py times) and the host's NumPy draws
+        res = []
+        for pipelined in (True, False):
+            gp = GP(kernel=exp_kernel2, jitter=1e-3, d=1)
+            vae = VAE(gp, [12, 9], 4, n, 40, 1e-3, 1, 7, 3, x, seed=3, dtype=torch.float64, pipelined=pipelined,
+                      hyper_sampler=sampler)
+            st = vae.svi_init()
+            st.params.mul_(5)
+            loss, st = vae.epoch_train(123, st)
+            res.append((loss.item(), st.params.clone(), vae.eval_test(9, st), st.t))
+        assert res[0][3] == res[1][3] == 7
+        assert abs(res[0][0] - res[1][0]) < 1e-10 * abs(res[0][0])
+        assert rel(res[0][1], res[1][1].cpu().numpy()) < 1e-10
+        assert abs(res[0][2] - res[1][2]) < 1e-10 * abs(res[0][2])
+        losses[sampler if isinstance(sampler, str) else "host"] = res[0][0]
+    assert losses["device"] != losses["host"]  # different generators: different (ls, var, sigma) sequences
+    assert VAE(GP(kernel=exp_kernel2, jitter=1e-3, d=1), [12, 9], 4, n, 40, 1e-3, 1, 7, 3, x)._engine().hyper_sampler == "device"
+    with pytest.raises(ValueError):
+        VAE(GP(kernel=exp_kernel2, jitter=1e-3, d=1), [12, 9], 4, n, 40, 1e-3, 1, 7, 3, x, hyper_sampler="host")
 
 
 def test_step_engine_2d_points_any_strides_and_kernel_guard():
@@ -657,3 +666,101 @@ def test_poigp_sample_against_oracle(tdt, ndt, tol):
         assert rel(out2["f"][i:i + 1], f_i) < 50 * tol
         tot, lam = out2["y"][good].double().sum().item(), out2["rate"][good].double().sum().item()
         assert (out2["y"][good] >= 0).all() and abs(tot - lam) < 6 * math.sqrt(lam)
+
+
+@pytest.mark.parametrize("tdt,tol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+def test_potentials_with_repeated_and_out_of_range_indices(tdt, tol):
+    """obs_idx / lik_idx may name a point twice (the reference's f[obs_idx] then counts it twice: inference.py:251-254,
+    392-396) — potential and gradient of gpvae_gp_potential and gpvae_vae_potential against the oracle with the
+    repeated observation written out, the same bits on every call; an index outside [0, n) is rejected on the host."""
+    from gp_vae_amd import ops
+    from gp_vae_amd._lib import GpvaeError
+    from gp_vae_amd.gp import exp_kernel2
+    from gp_vae_amd.inference import GPInference, VAEInference
+    rng = np.random.default_rng(4)
+    # ---- latent-f GP model on the whole grid, likelihood on f[idx] with repeats
+    n, C_ = 40, 3
+    x = np.arange(n) / n
+    idx = np.array([3, 17, 3, 25, 39, 17, 3, 0])
+    yv = np.sin(5 * x[idx]) + 0.1 * rng.standard_normal(len(idx))
+    uv, ul, us = rng.normal(0, 0.1, C_), np.log(rng.uniform(0.15, 0.4, C_)), np.log(rng.uniform(0.05, 0.2, C_))
+    jit = 1e-5 if tdt == torch.float64 else 1e-2  # float32: a nugget that keeps f^T K^-1 f within the 2e-4 bar
+    f = np.stack([np.linalg.cholesky(orc.exp_kernel2(x, x, np.exp(uv[c]), np.exp(ul[c]), jit)) @ rng.standard_normal(n) for c in range(C_)])
+    q = dev(np.concatenate([f, uv[:, None], ul[:, None], us[:, None]], 1), tdt)
+    xd, yd, idd = dev(x, tdt), dev(yv, tdt), torch.tensor(idx, device=DEV)
+    U, dU, info = ops.gp_potential(xd, q, yd, idd, jit)
+    U2, dU2, _ = ops.gp_potential(xd, q, yd, idd, jit)
+    assert torch.equal(U, U2) and torch.equal(dU, dU2) and int(info.abs().sum()) == 0
+
+    def pot(c, ff, a, b, g):  # oracle: MVN prior on all n points + one likelihood term PER OCCURRENCE in idx
+        full = orc.gp_regression_potential(x, ff, ff, a, b, g, jit)  # likelihood residuals zero: its constant terms only
+        r = (yv - ff[idx]) / np.exp(g)
+        m = len(idx)
+        return full + 0.5 * r @ r + (m - n) * g + 0.5 * (m - n) * np.log(2 * np.pi)
+    h = 1e-5
+    for c in range(C_):
+        u0 = pot(c, f[c], uv[c], ul[c], us[c])
+        assert abs(U[c].item() - u0) < tol * abs(u0)
+        if tdt == torch.float64:
+            for k in (3, 17, 5):  # thrice, twice and never observed
+                e = np.zeros(n); e[k] = h
+                fd = (pot(c, f[c] + e, uv[c], ul[c], us[c]) - pot(c, f[c] - e, uv[c], ul[c], us[c])) / (2 * h)
+                assert abs(dU[c, k].item() - fd) < 1e-4 * max(1.0, abs(fd)), (c, k)
+            fd = (pot(c, f[c], uv[c], ul[c], us[c] + h) - pot(c, f[c], uv[c], ul[c], us[c] - h)) / (2 * h)
+            assert abs(dU[c, n + 2].item() - fd) < 1e-4 * max(1.0, abs(fd))
+    # the torch composition of the same model (GPInference._gp_potential) agrees, repeats included
+    y_full = np.full(n, np.nan); y_full[idx] = yv
+    inf = GPInference(exp_kernel2, 1, x, y_full, idx, {}, dtype=tdt)
+    if tdt == torch.float64:  # (the composition's nugget is the reference's fixed 1e-5)
+        Ug, dF, dV, dL, dS = inf._gp_potential(xd, yd, idd, q[:, :n], q[:, n], q[:, n + 1], q[:, n + 2])
+        assert rel(Ug, U.cpu().numpy()) < tol and rel(dF, dU[:, :n].cpu().numpy()) < 10 * tol
+    for bad in ([3, 40], [-1, 2]):
+        with pytest.raises(GpvaeError):
+            ops.gp_potential(xd, q, yd[:2].contiguous(), torch.tensor(bad, device=DEV))
+        with pytest.raises(GpvaeError):
+            GPInference(exp_kernel2, 1, x, y_full, bad, {}, dtype=tdt)
+    # ---- decoder-prior model: gathered columns, repeats and range
+    nd, dims, chains = 30, (9, 7, 4), 5
+    p = orc.init_params(np.random.default_rng(1), nd, *dims, np.float64)
+    p = {k: 20 * v for k, v in p.items()}
+    dec_flat = dev(np.concatenate([p[k].reshape(-1) for k in ("V1", "c1", "V2", "c2", "V3", "c3")]), tdt)
+    oi = np.array([4, 11, 4, 29, 0, 11])
+    yo = rng.standard_normal(len(oi))
+    zz, lsg = rng.standard_normal((chains, dims[2])), np.log(rng.uniform(0.05, 0.3, chains))
+    qd = dev(np.concatenate([zz, lsg[:, None]], 1), tdt)
+    assert ops.vae_potential_supported(tdt, dims[0], dims[1], dims[2], len(oi))
+    Uv, dUv = ops.vae_potential(dec_flat, qd, dev(yo, tdt), torch.tensor(oi, device=DEV), nd, dims[0], dims[1])
+
+    def vpot(zc, lc):  # the oracle takes y as a full vector: evaluate one occurrence at a time and add the repeats by hand
+        sig = np.exp(lc)
+        fdec = orc.decoder(p, zc[None])[0]
+        r = fdec[oi] - yo
+        loglik = np.sum(-0.5 * (r / sig) ** 2 - lc - 0.5 * np.log(2 * np.pi))
+        logpz = np.sum(-0.5 * zc ** 2 - 0.5 * np.log(2 * np.pi))
+        logps = np.log(2.0) - 0.5 * np.log(2 * np.pi) - np.log(0.1) - 0.5 * (sig / 0.1) ** 2 + lc
+        return -(loglik + logpz + logps)
+    for c in range(chains):
+        u0 = vpot(zz[c], lsg[c])
+        assert abs(Uv[c].item() - u0) < tol * max(1.0, abs(u0))
+        if tdt == torch.float64:
+            e = np.zeros(dims[2]); e[1] = h
+            fd = (vpot(zz[c] + e, lsg[c]) - vpot(zz[c] - e, lsg[c])) / (2 * h)
+            assert abs(dUv[c, 1].item() - fd) < 1e-4 * max(1.0, abs(fd))
+    # without repeats the hand-written potential above IS oracle.vae_potential (pins the restatement used here)
+    uniq = np.array([4, 11, 29])
+    y_u = np.zeros(nd); y_u[uniq] = yo[[0, 1, 3]]
+    oi_keep, yo_keep = oi, yo
+    oi, yo = uniq, yo_keep[[0, 1, 3]]
+    assert abs(np.ravel(orc.vae_potential(p, zz[:1], lsg[:1], y_u, uniq))[0] - vpot(zz[0], lsg[0])) < 1e-9 * abs(vpot(zz[0], lsg[0]))
+    oi, yo = oi_keep, yo_keep
+    dec_list = [(dev(p["V1"], tdt), dev(p["c1"], tdt)), (), (dev(p["V2"], tdt), dev(p["c2"], tdt)), (), (dev(p["V3"], tdt), dev(p["c3"], tdt))]
+    yfull = np.full(nd, np.nan); yfull[oi] = yo  # last occurrence wins in this vector: only used for shapes below
+    for bad in ([4, 30], [-2, 3]):
+        with pytest.raises(GpvaeError):
+            ops.vae_potential(dec_flat, qd, dev(yo[:2], tdt), torch.tensor(bad, device=DEV), nd, dims[0], dims[1])
+        with pytest.raises(GpvaeError):
+            VAEInference(None, dec_list, dims[2], 1, np.arange(nd) / nd, yfull, bad, {}, dtype=tdt)
+    # the composed path (decoder forward + glue + VJP) handles repeats the same way
+    inf = VAEInference(None, dec_list, dims[2], 1, np.arange(nd) / nd, yfull, oi, {}, dtype=tdt)
+    Uc, dz, du = inf._potential(qd[:, :dims[2]], qd[:, dims[2]], dev(yo, tdt), torch.tensor(oi, device=DEV))
+    assert rel(Uc, Uv.cpu().numpy()) < 10 * tol and rel(dz, dUv[:, :dims[2]].cpu().numpy()) < 50 * tol
