@@ -435,7 +435,7 @@ class VAEInference(Inference):
         if ops.vae_potential_supported(self.dtype, self.h0, self.h1, self.z_dim, self.obs_idx.numel()):
             q = torch.cat([zz, _as_device(log_sigma, self.dtype).reshape(-1, 1)], 1)
             U, dU = ops.vae_potential(self.dec_flat, q, self.y[self.obs_idx].contiguous(), self.obs_idx.contiguous(),
-                                      self.n_out, self.h0, self.h1)
+                                      self.n_out, self.h0, self.h1, checked=True)  # obs_idx was checked in __init__
             return U, dU[:, :self.z_dim], dU[:, self.z_dim]
         return self._potential(z, log_sigma, self.y[self.obs_idx], self.obs_idx)
 
