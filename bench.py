@@ -231,14 +231,20 @@ def extras(ops, x, dev, out=None):
     y5[[20, 23, 100, 110, 117, 130, 133, 140, 170, 190]] = np.sin(6 * x5[[20, 23, 100, 110, 117, 130, 133, 140, 170, 190]])
     inf = VAEInference(None, dec, dims5[2], 1, x5, y5, [20, 23, 100, 110, 117, 130, 133, 140, 170, 190],
                        {"num_warmup": 100, "num_samples": 100, "num_chains": 1024, "thinning": 1}, seed=1, dtype=torch.float32)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    inf.run_mcmc(3)
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
+    walls = []
+    for rep in range(2):  # the first call of a process also loads the kernels' code objects: both are reported
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        inf.run_mcmc(3)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    t = walls[1]
     lf = float(inf.mcmc_info["leapfrogs_per_iteration"].mean().item())
-    out["c5_nuts"] = {"workload": "C5 end to end: run_mcmc, batched NUTS, 1024 chains, 100 warm-up + 100 sampling iterations",
-                      "wall_s": t, "chain_iterations_per_s": 1024 * 200 / t, "leapfrogs_per_iteration": lf,
+    out["c5_nuts"] = {"workload": "C5 end to end: run_mcmc (warm-up with adaptation + sampling + unpacking the sites), batched NUTS, "
+                                  "1024 chains, 100 warm-up + 100 sampling iterations; the whole run is one launch of "
+                                  "gpvae_nuts_vae_run",
+                      "wall_s": t, "wall_s_first_call_of_the_process": walls[0],
+                      "chain_iterations_per_s": 1024 * 200 / t, "leapfrogs_per_iteration": lf,
                       "accept_prob": float(inf.mcmc_info["accept_prob"].mean().item()),
                       "divergent": int(inf.mcmc_info["divergent"])}
     # C3 again with the opt-in fp16 x 2 draw and factorisation (StepEngine(mfma="f16x2"): operands of the two

@@ -74,6 +74,9 @@ SIGNATURES = {
     "gpvae_randn_h2": (_i, [_vp, _i64, _u64, _u64, _vp, _i64]),
     "gpvae_draw_h2": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64]),
     "gpvae_nuts_op": (_i, [_vp, _i, _i, _i64, _i64, _i, _i, _i, _i, _i, _vp]),
+    "gpvae_nuts_vae_supported": (_i, [_i, _i, _i, _i, _i64]),
+    "gpvae_nuts_vae_iteration": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _d]),
+    "gpvae_nuts_vae_run": (_i, [_vp, _i, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _d]),
     "gpvae_decoder_vjp_static": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 

@@ -105,4 +105,22 @@ template <> struct Mfma16<double> {
   __device__ static __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
 
+// The scalar part of VAEInference.regression's potential (src/model/inference.py:243-254 in NumPyro's unconstrained
+// space), shared by vae_potential_kernel (vae.hip) and the fused NUTS iteration (nuts.hip) so that both evaluate it
+// with the very same operations: sq = sum of squared residuals at the observed columns, zz = |z|^2, u = log noise.
+// Returns U; du = dU/du; iv = 1 / sigma^2 (the scale of the residuals' gradient).
+template <typename T>
+__device__ __forceinline__ T vae_potential_scalar(T sq, T zz, T u, T s0p, int n_obs, int z, T &du, T &iv) {
+#pragma clang fp contract(off)  // no fused multiply-adds here: which products fuse depends on the inlining context,
+                                // and the two callers must agree to the last bit (chains are compared bit for bit)
+  const T sigma = dexp<T>(u);
+  iv = T(1) / (sigma * sigma);
+  const T hl2p = T(0.9189385332046727), rs = sigma / s0p;
+  const T log_lik = T(-0.5) * sq * iv - (T)n_obs * (u + hl2p);
+  const T log_pz = T(-0.5) * zz - (T)z * hl2p;
+  const T log_ps = T(0.6931471805599453) - hl2p - (T)log((double)s0p) - T(0.5) * rs * rs + u;
+  du = rs * rs - T(1) + (T)n_obs - sq * iv;
+  return -(log_lik + log_pz + log_ps);
+}
+
 }  // namespace gpvae

@@ -1026,16 +1026,13 @@ __global__ __launch_bounds__(NTHREADS) void vae_potential_kernel(
   __syncthreads();
   if (tid < rows) {  // one lane per chain: the scalar part of the potential
     const int r = tid;
-    const T u = su[r], sigma = dexp<T>(u), iv = T(1) / (sigma * sigma);
+    const T u = su[r];
     T sq = T(0), zz = T(0);
     for (int j = 0; j < n_obs; ++j) sq += R[r * n_obs + j] * R[r * n_obs + j];
     for (int j = 0; j < z; ++j) zz += Zb[r * z + j] * Zb[r * z + j];
-    const T hl2p = T(0.9189385332046727), rs = sigma / s0p;
-    const T log_lik = T(-0.5) * sq * iv - (T)n_obs * (u + hl2p);
-    const T log_pz = T(-0.5) * zz - (T)z * hl2p;
-    const T log_ps = T(0.6931471805599453) - hl2p - (T)log((double)s0p) - T(0.5) * rs * rs + u;
-    U[c0 + r] = -(log_lik + log_pz + log_ps);
-    dU[(c0 + r) * lddu + z] = rs * rs - T(1) + (T)n_obs - sq * iv;
+    T du, iv;
+    U[c0 + r] = vae_potential_scalar<T>(sq, zz, u, s0p, n_obs, z, du, iv);
+    dU[(c0 + r) * lddu + z] = du;
     su[r] = iv;
   }
   __syncthreads();

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from . import ops
 from .hmc import hmc
-from .nuts import nuts, nuts_device, uniforms_per_iteration
+from .nuts import nuts, nuts_device, nuts_device_run, uniforms_per_iteration
 from ._lib import GpvaeError
 from .gp import _as_device, _key_parts, _seed_of, exp_kernel2
 from .parallel import dist_info, shard
@@ -120,10 +120,22 @@ class Inference():
 
         if kernel == "nuts":
             # the transition runs in libgpvae_hip (gpvae_nuts_op); "nuts_driver": "torch" keeps the torch restatement
-            run = nuts if a.get("nuts_driver", "device") == "torch" else nuts_device
-            smp, info = run(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
-                             thinning=int(a.get("thinning", 1)), max_tree_depth=depth, seed=seed + 1,
-                             noise_fn=noise_fn)
+            # "nuts_driver": "device" (default: the whole run as ONE launch where the potential offers it —
+            # gpvae_nuts_vae_run — else as "iteration"), "iteration" (one fused launch per iteration where offered:
+            # gpvae_nuts_vae_iteration, adaptation as torch operations), "lockstep" (gpvae_nuts_op around the
+            # potential, all chains in lock step), "torch" (the torch restatement).  Same noise in all four.
+            driver = a.get("nuts_driver", "device")
+            if driver not in ("device", "iteration", "lockstep", "torch"):
+                raise ValueError("mcmc_args['nuts_driver'] must be 'device', 'iteration', 'lockstep' or 'torch'")
+            if driver == "device" and hasattr(potential, "nuts_run"):
+                smp, info = nuts_device_run(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
+                                            thinning=int(a.get("thinning", 1)), max_tree_depth=depth,
+                                            noise_seed=seed + 1, noise_stream_base=0x1418 << 32, chain_ids=rows)
+            else:
+                kw = {} if driver == "torch" else {"fused": driver in ("device", "iteration")}
+                smp, info = (nuts if driver == "torch" else nuts_device)(
+                    potential, start, int(a["num_warmup"]), int(a["num_samples"]), thinning=int(a.get("thinning", 1)),
+                    max_tree_depth=depth, seed=seed + 1, noise_fn=noise_fn, **kw)
         else:
             smp, info = hmc(potential, start, int(a["num_warmup"]), int(a["num_samples"]),
                             thinning=int(a.get("thinning", 1)), num_leapfrog=int(a.get("num_leapfrog", 16)),
@@ -407,7 +419,22 @@ class VAEInference(Inference):
                 if rc:
                     _lib.check(rc, "gpvae_vae_potential")
 
-        return Potential(fn, q0, unpack, eval_into)
+        pot = Potential(fn, q0, unpack, eval_into)
+        if fused and lib.gpvae_nuts_vae_supported(dtc, self.h0, self.h1, zd, n_obs):
+            def nuts_iteration(stream_handle, dtc_, chains, max_depth, buffers):
+                rc = lib.gpvae_nuts_vae_iteration(stream_handle, dtc_, chains, max_depth, buffers, n_out, h0, h1, zd,
+                                                  p_dec, p_y, p_idx, n_obs, 0.1)
+                if rc:
+                    _lib.check(rc, "gpvae_nuts_vae_iteration")
+            pot.nuts_iteration = nuts_iteration  # one launch per NUTS iteration (gp_vae_amd.nuts.nuts_device)
+
+            def nuts_run(stream_handle, dtc_, chains, run_desc):
+                rc = lib.gpvae_nuts_vae_run(stream_handle, dtc_, chains, run_desc, n_out, h0, h1, zd, p_dec, p_y, p_idx,
+                                            n_obs, 0.1)
+                if rc:
+                    _lib.check(rc, "gpvae_nuts_vae_run")
+            pot.nuts_run = nuts_run  # the whole run in one launch (gp_vae_amd.nuts.nuts_device_run)
+        return pot
 
     def fit(self, plot=False, rng_key=None, num_prior=1000):
         """Prior and posterior predictive draws y_pred ~ Normal(decoder(z), noise)

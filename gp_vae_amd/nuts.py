@@ -245,10 +245,13 @@ class _Buffers(C.Structure):
 
 
 def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max_tree_depth=10, step_size=0.1,
-                target_accept=0.8, seed=0, noise_fn=None, adapt_mass_matrix=True):
+                target_accept=0.8, seed=0, noise_fn=None, adapt_mass_matrix=True, fused=True):
     """The same sampler with the transition in libgpvae_hip (gpvae_nuts_op: one wave per chain, two launches
     per leapfrog step around the caller's potential instead of ~40 elementwise torch kernels).  Same
-    arguments, results and random-number consumption as :func:`nuts`; q0 must be a device tensor."""
+    arguments, results and random-number consumption as :func:`nuts`; q0 must be a device tensor.
+    fused (default): a potential with a `nuts_iteration` hook (VAEInference.regression's, whose decoder head
+    fits LDS) runs every iteration as one launch of gpvae_nuts_vae_iteration — same chains, to rounding;
+    fused=False keeps the lock-step gpvae_nuts_op driver."""
     from . import _lib
     from ._lib import check
     from .ops import _dt
@@ -302,6 +305,13 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
         Un_buf, gn_buf = sca(), vec()
         b.Un, b.gn, b.ldg = Un_buf.data_ptr(), gn_buf.data_ptr(), gn_buf.stride(0)
 
+    # a potential that brings its own fused iteration (VAEInference.regression: gpvae_nuts_vae_iteration) runs the
+    # whole transition — every doubling and leapfrog step of every chain — as ONE launch per iteration
+    iterate = getattr(potential_and_grad, "nuts_iteration", None) if fused else None
+    if iterate is not None and (eval_into is None):
+        Un_buf, gn_buf = sca(), vec()  # the fused kernel's scratch
+        b.Un, b.gn, b.ldg = Un_buf.data_ptr(), gn_buf.data_ptr(), gn_buf.stride(0)
+
     keep = []
     acc_stat = torch.zeros(Cn, dtype=dt, device=dev)
     n_div = torch.zeros((), dtype=torch.long, device=dev)
@@ -324,8 +334,11 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
             z, unif = noise_fn(it)
             t["z"].copy_(z)
             t["unif"].copy_(unif)
-        op(0)
-        for depth in range(max_tree_depth):
+        if iterate is not None:
+            iterate(h_stream, dtc, Cn, max_tree_depth, bp)
+        else:
+            op(0)
+        for depth in range(max_tree_depth if iterate is None else 0):
             op(1, depth)
             leaves = 1 << depth
             for leaf in range(leaves):
@@ -347,7 +360,8 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
             op(4, depth)
             if int(t["flags"][1].item()) == 0:
                 break
-        op(5)
+        if iterate is None:
+            op(5)
         a = t["accept"]
         if warm:
             ad.update(it, a.clone(), q.clone())
@@ -361,4 +375,60 @@ def nuts_device(potential_and_grad, q0, num_warmup, num_samples, thinning=1, max
     info = {"accept_prob": acc_stat / max(num_samples, 1), "step_size": ad.step_size(False),
             "inverse_mass": ad.minv, "divergent": int(n_div.item()),
             "leapfrogs_per_iteration": n_leap / max(num_samples, 1)}
+    return samples, info
+
+
+class _Run(C.Structure):
+    """gpvae_nuts_run of include/gpvae.h."""
+    _fields_ = [("num_warmup", C.c_int32), ("num_samples", C.c_int32), ("thinning", C.c_int32), ("adapt_mass", C.c_int32),
+                ("max_depth", C.c_int32), ("win_start", C.c_int32), ("n_ends", C.c_int32), ("ends", C.c_int32 * 24),
+                ("seed", C.c_uint64), ("stream_base", C.c_uint64), ("row_len", C.c_int64), ("chain_ids", C.c_void_p),
+                ("step_size", C.c_double), ("target_accept", C.c_double), ("q0", C.c_void_p), ("samples", C.c_void_p),
+                ("accept_prob", C.c_void_p), ("leapfrogs", C.c_void_p), ("step_size_out", C.c_void_p),
+                ("inverse_mass", C.c_void_p), ("divergent", C.c_void_p)]
+
+
+def nuts_device_run(potential, q0, num_warmup, num_samples, thinning=1, max_tree_depth=10, step_size=0.1,
+                    target_accept=0.8, noise_seed=0, noise_stream_base=0, chain_ids=None, adapt_mass_matrix=True):
+    """The whole run — warm-up with its adaptation and sampling, every chain on its own — as ONE launch, for
+    potentials that bring a `nuts_run` hook (VAEInference.regression with a decoder head that fits LDS:
+    gpvae_nuts_vae_run).  Same algorithm and the same random numbers as :func:`nuts_device` driven with the Philox
+    noise of Inference._mcmc: element (chain_ids[c], k) of the [chains, D + uniforms_per_iteration] normal matrix of
+    stream `noise_stream_base | iteration`, uniforms = Phi(normal).  The adaptation arithmetic runs per chain in the
+    chains' dtype inside the kernel; the per-iteration drivers do it as torch operations, so the two agree to
+    rounding at first and like two runs of one sampler with slightly different step sizes after long warm-ups.
+    Returns (samples [ceil(num_samples / thinning), C, D], info) as nuts_device does."""
+    from . import _lib
+    from ._lib import check
+    from .ops import _dt
+    run = getattr(potential, "nuts_run", None)
+    if run is None:
+        raise _lib.GpvaeError("nuts_device_run: this potential has no whole-run kernel (use nuts_device)")
+    q0 = q0.contiguous()
+    Cn, D = q0.shape
+    dev, dt = q0.device, q0.dtype
+    win = _Windows(num_warmup if adapt_mass_matrix else 0)
+    if len(win.ends) > 24:
+        raise _lib.GpvaeError("nuts_device_run: more than 24 mass-matrix windows")
+    kept = (num_samples + thinning - 1) // thinning
+    samples = torch.empty((kept, Cn, D), dtype=dt, device=dev)
+    acc, leap, eps = (torch.empty(Cn, dtype=dt, device=dev) for _ in range(3))
+    minv = torch.empty((Cn, D), dtype=dt, device=dev)
+    ndiv = torch.zeros(Cn, dtype=torch.int32, device=dev)
+    ids = None if chain_ids is None else chain_ids.to(device=dev, dtype=torch.long).contiguous()
+    r = _Run()
+    r.num_warmup, r.num_samples, r.thinning, r.adapt_mass = int(num_warmup), int(num_samples), int(thinning), int(bool(win.ends))
+    r.max_depth, r.win_start, r.n_ends = int(max_tree_depth), int(win.start), len(win.ends)
+    for i, e in enumerate(win.ends):
+        r.ends[i] = int(e)
+    r.seed, r.stream_base = int(noise_seed) & 0xFFFFFFFFFFFFFFFF, int(noise_stream_base) & 0xFFFFFFFFFFFFFFFF
+    r.row_len = D + uniforms_per_iteration(max_tree_depth)
+    r.chain_ids = None if ids is None else ids.data_ptr()
+    r.step_size, r.target_accept = float(step_size), float(target_accept)
+    r.q0, r.samples = q0.data_ptr(), samples.data_ptr()
+    r.accept_prob, r.leapfrogs, r.step_size_out = acc.data_ptr(), leap.data_ptr(), eps.data_ptr()
+    r.inverse_mass, r.divergent = minv.data_ptr(), ndiv.data_ptr()
+    run(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), _dt(q0), Cn, C.byref(r))
+    info = {"accept_prob": acc, "step_size": eps, "inverse_mass": minv, "divergent": int(ndiv.sum().item()),
+            "leapfrogs_per_iteration": leap}
     return samples, info

@@ -393,6 +393,47 @@ typedef struct gpvae_nuts_buffers {
 int gpvae_nuts_op(void *stream, int dtype, int op, int64_t C, int64_t D, int max_depth, int depth, int leaf,
                   int ck_lo, int ck_hi, const gpvae_nuts_buffers *b);
 
+/* ---- f4 + a11 fused: one whole NUTS iteration of VAEInference.regression per launch ------------------
+ * Replaces mcmc.run's inner loop for the decoder-prior model (src/model/inference.py:84-95 driving
+ * inference.py:235-254) — what gpvae_nuts_op (INIT, then per doubling BEGIN, per leapfrog step PRE /
+ * potential / POST, MERGE; ACCEPT) and gpvae_vae_potential do in ~2 launches per leapfrog step — as ONE
+ * launch per iteration: four chains per workgroup, one wave each, the decoder's head and the output layer
+ * gathered at obs_idx in LDS; every chain runs to the end of its own tree (no lock step with the deepest
+ * tree of the batch).  Same phases, uniforms (unif[:, ...] indexed by depth and leaf) and arithmetic per
+ * chain as the lock-step driver.  D = z + 1: q = (z, log noise).  b->Un [C] and b->gn [C, ldg] are the
+ * kernel's scratch here; b->flags is not used.  Decoders whose head does not fit 64 KB of LDS:
+ * gpvae_nuts_vae_supported() == 0, drive gpvae_nuts_op around gpvae_vae_potential instead.             */
+int gpvae_nuts_vae_supported(int dtype, int h0, int h1, int z, int64_t n_obs);
+int gpvae_nuts_vae_iteration(void *stream, int dtype, int64_t C, int max_depth, const gpvae_nuts_buffers *b,
+                             int64_t n, int h0, int h1, int z, const void *dec_params, const void *y_obs,
+                             const int64_t *obs_idx, int64_t n_obs, double noise_scale);
+
+/* ---- f4 + a11: a whole MCMC run of VAEInference.regression in ONE launch -----------------------------
+ * Replaces mcmc.run(rng_key, y, obs_idx) for the decoder-prior model (src/model/inference.py:84-95 with
+ * the model of inference.py:235-254): num_warmup + num_samples NUTS iterations of every chain — chains are
+ * independent, so each wave takes ITS chain through the whole run: transitions as in
+ * gpvae_nuts_vae_iteration, the iteration's normals and uniforms drawn in place from the Philox stream
+ * (seed, stream_base | iteration) at element chain_ids[c] * row_len + k (the numbers gpvae_randn writes
+ * there; uniform = Phi(normal)), dual-averaging step size and a diagonal mass matrix over Stan's warm-up
+ * windows per chain.  The launch lasts as long as the chain with the most leapfrog steps over the whole
+ * run, not the deepest tree of every iteration.  Outputs: samples [ceil(num_samples / thinning)][C][D]
+ * (D = z + 1: z, log noise), per chain the mean acceptance statistic and leapfrog steps per sampling
+ * iteration, the adapted step size, inverse mass diagonal [C, D] and the number of divergent transitions. */
+typedef struct gpvae_nuts_run {
+  int32_t num_warmup, num_samples, thinning, adapt_mass, max_depth;
+  int32_t win_start, n_ends, ends[24]; /* mass-matrix windows: first adapted iteration, last iteration of each window */
+  uint64_t seed, stream_base;
+  int64_t row_len;                     /* >= D + 2 max_depth + 2^max_depth - 1 */
+  const int64_t *chain_ids;            /* [C] global chain ids (device), or NULL: 0 .. C-1 */
+  double step_size, target_accept;
+  const void *q0;                      /* [C, D] start points */
+  void *samples, *accept_prob, *leapfrogs, *step_size_out, *inverse_mass;
+  int32_t *divergent;
+} gpvae_nuts_run;
+int gpvae_nuts_vae_run(void *stream, int dtype, int64_t C, const gpvae_nuts_run *r, int64_t n, int h0, int h1,
+                       int z, const void *dec_params, const void *y_obs, const int64_t *obs_idx, int64_t n_obs,
+                       double noise_scale);
+
 /* ---- the same VJP with no workspace argument and no allocation ------------------------------------
  * No counterpart in the reference.  For callers that cannot allocate or carry a workspace: code
  * under HIP graph capture, tight MCMC / serving loops, harnesses that forbid hipMalloc.  Same kernels

@@ -764,3 +764,98 @@ def test_potentials_with_repeated_and_out_of_range_indices(tdt, tol):
     inf = VAEInference(None, dec_list, dims[2], 1, np.arange(nd) / nd, yfull, oi, {}, dtype=tdt)
     Uc, dz, du = inf._potential(qd[:, :dims[2]], qd[:, dims[2]], dev(yo, tdt), torch.tensor(oi, device=DEV))
     assert rel(Uc, Uv.cpu().numpy()) < 10 * tol and rel(dz, dUv[:, :dims[2]].cpu().numpy()) < 50 * tol
+
+
+@pytest.mark.parametrize("tdt", [torch.float64, torch.float32])
+def test_fused_nuts_iteration_matches_the_lockstep_driver(tdt):
+    """gpvae_nuts_vae_iteration (one launch per NUTS iteration: every chain runs its own tree to its end, the
+    decoder-prior potential inside the wave) against the lock-step driver (gpvae_nuts_op around
+    gpvae_vae_potential) on the same normals and uniforms: same trees (leapfrog counts, divergences), same
+    adaptation, positions equal to rounding; a chain does not depend on the batch it runs in (ragged chain count:
+    the last workgroup is partly empty); a decoder too wide for LDS falls back to the lock-step driver."""
+    from gp_vae_amd import _lib
+    from gp_vae_amd.inference import VAEInference
+    rng = np.random.default_rng(8)
+    n, dims = 300, (35, 30, 10)  # the reference's 1-D decoder (toy_examples.py:615-630)
+    p = {k: 18 * v for k, v in orc.init_params(np.random.default_rng(2), n, *dims, np.float64).items()}
+    dec = [(dev(p["V1"], tdt), dev(p["c1"], tdt)), (), (dev(p["V2"], tdt), dev(p["c2"], tdt)), (), (dev(p["V3"], tdt), dev(p["c3"], tdt))]
+    x = np.arange(n) / n
+    obs = [20, 23, 100, 110, 117, 130, 133, 140, 170, 190]  # toy_examples.py:199
+    y = np.full(n, np.nan)
+    y[obs] = orc.decoder(p, rng.standard_normal((1, dims[2])))[0][obs] + 0.05 * rng.standard_normal(len(obs))
+    its = (30, 12)
+    res = {}
+    for driver in ("iteration", "lockstep"):
+        args = {"num_warmup": its[0], "num_samples": its[1], "num_chains": 13, "thinning": 1, "max_tree_depth": 6,
+                "nuts_driver": driver}
+        inf = VAEInference(None, dec, dims[2], 1, x, y, obs, args, seed=3, dtype=tdt)
+        pot = inf.regression(y=inf.y, obs_idx=inf.obs_idx)
+        assert hasattr(pot, "nuts_iteration")
+        smp, info = inf._mcmc(11, pot)
+        res[driver] = (smp, info)
+    a, b = res["iteration"], res["lockstep"]
+    assert a[0].shape == b[0].shape == (13 * its[1], dims[2] + 1) and torch.isfinite(a[0]).all()
+    assert torch.equal(a[1]["leapfrogs_per_iteration"], b[1]["leapfrogs_per_iteration"]) and a[1]["divergent"] == b[1]["divergent"]
+    assert a[1]["leapfrogs_per_iteration"].max().item() > 3  # real trees, not one-step trajectories
+    # bit for bit: the wave-level potential inside the fused kernel evaluates gpvae_vae_potential's expressions in its
+    # order (the scalar part is one shared function compiled without fused multiply-adds), and every phase is the
+    # same device function in both drivers — anything less would not survive the warm-up's adaptation, which
+    # amplifies a last-bit difference of one acceptance statistic about 5x per iteration
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1]["step_size"], b[1]["step_size"])
+    assert torch.equal(a[1]["inverse_mass"], b[1]["inverse_mass"])
+    lib = _lib.load()
+    assert lib.gpvae_nuts_vae_supported(0, 35, 30, 10, 10) == 1 and lib.gpvae_nuts_vae_supported(1, 2000, 30, 10, 10) == 0
+    wide = orc.init_params(np.random.default_rng(2), 40, 600, 30, 4, np.float64)  # h0 = 600: 18 k floats of V2 alone
+    decw = [(dev(wide["V1"], tdt), dev(wide["c1"], tdt)), (), (dev(wide["V2"], tdt), dev(wide["c2"], tdt)), (), (dev(wide["V3"], tdt), dev(wide["c3"], tdt))]
+    yw = np.full(40, np.nan); yw[[3, 9]] = 0.1
+    infw = VAEInference(None, decw, 4, 1, np.arange(40) / 40, yw, [3, 9], {"num_warmup": 2, "num_samples": 2, "num_chains": 3}, dtype=tdt)
+    assert not hasattr(infw.regression(y=infw.y, obs_idx=infw.obs_idx), "nuts_iteration")
+    out = infw.run_mcmc(1)
+    assert out["z"].shape == (6, 4) and torch.isfinite(out["z"]).all()
+
+
+def test_whole_run_nuts_kernel_matches_the_per_iteration_driver():
+    """gpvae_nuts_vae_run (warm-up, adaptation and sampling of every chain in ONE launch, noise drawn in place from
+    the Philox stream) against the per-iteration driver: without warm-up the chains are the same chains (same
+    normals, same uniforms, same transitions); with a short warm-up they agree to the rounding of the adaptation
+    arithmetic; over a long run the two are two runs of one sampler (posterior moments, acceptance, step sizes)."""
+    from gp_vae_amd.inference import VAEInference
+    rng = np.random.default_rng(8)
+    n, dims = 300, (35, 30, 10)
+    p = {k: 18 * v for k, v in orc.init_params(np.random.default_rng(2), n, *dims, np.float64).items()}
+    x = np.arange(n) / n
+    obs = [20, 23, 100, 110, 117, 130, 133, 140, 170, 190]
+    y = np.full(n, np.nan)
+    y[obs] = orc.decoder(p, rng.standard_normal((1, dims[2])))[0][obs] + 0.05 * rng.standard_normal(len(obs))
+
+    def run(tdt, driver, warm, ns, chains, thin=1, depth=6):
+        dec = [(dev(p["V1"], tdt), dev(p["c1"], tdt)), (), (dev(p["V2"], tdt), dev(p["c2"], tdt)), (), (dev(p["V3"], tdt), dev(p["c3"], tdt))]
+        args = {"num_warmup": warm, "num_samples": ns, "num_chains": chains, "thinning": thin, "max_tree_depth": depth,
+                "nuts_driver": driver}
+        inf = VAEInference(None, dec, dims[2], 1, x, y, obs, args, seed=3, dtype=tdt)
+        pot = inf.regression(y=inf.y, obs_idx=inf.obs_idx)
+        assert hasattr(pot, "nuts_run")
+        smp, info = inf._mcmc(11, pot)
+        return smp, info
+    for tdt, tol in ((torch.float64, 1e-12), (torch.float32, 1e-5)):
+        a, ia = run(tdt, "device", 0, 7, 13, thin=2)
+        b, ib = run(tdt, "iteration", 0, 7, 13, thin=2)
+        assert a.shape == b.shape == (13 * 4, dims[2] + 1)
+        # (means over the sampling iterations: torch divides by multiplying with the reciprocal, the kernel divides)
+        assert torch.allclose(ia["leapfrogs_per_iteration"], ib["leapfrogs_per_iteration"], rtol=1e-6) and ia["divergent"] == ib["divergent"]
+        assert ((a - b).abs().max() / b.abs().max()).item() < tol, tdt
+        assert torch.allclose(ia["accept_prob"], ib["accept_prob"], rtol=1e-5)
+    a, ia = run(torch.float64, "device", 8, 4, 13)
+    b, ib = run(torch.float64, "iteration", 8, 4, 13)
+    assert ((a - b).abs().max() / b.abs().max()).item() < 1e-6
+    assert torch.allclose(ia["step_size"], ib["step_size"], rtol=1e-9) and torch.allclose(ia["inverse_mass"], ib["inverse_mass"], rtol=1e-9)
+    # a long run with mass-matrix windows: the same sampler statistically
+    a, ia = run(torch.float32, "device", 150, 100, 256, depth=8)
+    b, ib = run(torch.float32, "iteration", 150, 100, 256, depth=8)
+    assert torch.isfinite(a).all() and a.shape == b.shape == (256 * 100, dims[2] + 1)
+    sd = b.std(0)
+    assert ((a.mean(0) - b.mean(0)).abs() / sd).max().item() < 0.15
+    assert ((a.std(0) / sd) - 1).abs().max().item() < 0.15
+    assert abs(ia["accept_prob"].mean().item() - ib["accept_prob"].mean().item()) < 0.03 and 0.6 < ia["accept_prob"].mean().item() < 0.95
+    assert abs(ia["step_size"].log().mean().item() - ib["step_size"].log().mean().item()) < 0.1
+    assert abs(ia["inverse_mass"].log().mean().item() - ib["inverse_mass"].log().mean().item()) < 0.2
