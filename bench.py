@@ -247,6 +247,28 @@ def extras(ops, x, dev, out=None):
                       "chain_iterations_per_s": 1024 * 200 / t, "leapfrogs_per_iteration": lf,
                       "accept_prob": float(inf.mcmc_info["accept_prob"].mean().item()),
                       "divergent": int(inf.mcmc_info["divergent"])}
+    # f2: the reference's vmap of gp_prediction over posterior draws (inference.py:511-521): S = 8000 draws on the 25 x 25
+    # grid, n_obs = 10 (toy_examples.py:199) and 100 observed points; one workgroup per problem, everything in LDS
+    g25 = np.arange(25) / 25.0
+    u25, v25 = np.meshgrid(g25, g25)
+    x25 = np.stack([u25.ravel(), v25.ravel()], 1).astype(np.float32)
+    rng = np.random.default_rng(0)
+    S = 8000
+    hv, hl, hs = rng.lognormal(0, 0.1, S), rng.uniform(0.05, 0.5, S), np.abs(rng.normal(0, 0.1, S)) + 1e-3
+    f2 = {}
+    for n_obs in (10, 100):
+        obs = np.sort(rng.permutation(625)[:n_obs])
+        mask = np.ones(625, bool); mask[obs] = False
+        yy = np.sin(4 * x25.sum(1)) + 0.1 * rng.standard_normal(625)
+        xo, xt = torch.tensor(x25[obs], device=dev), torch.tensor(x25[mask], device=dev)
+        yo = torch.tensor(yy[obs], dtype=torch.float32, device=dev)
+        xi = ops.randn((S, int(mask.sum())), torch.float32, dev, seed=9)
+        t = _event_time(lambda: ops.krig_predict_batched(xo, xt, yo, hv, hl, hs, 1e-5, xi), 3)
+        info = ops.krig_predict_batched(xo, xt, yo, hv, hl, hs, 1e-5, xi)[3]
+        f2["n_obs_%d" % n_obs] = {"problems_per_s": S / t, "ms": t * 1e3, "n_test": int(mask.sum()),
+                                  "all_pd": bool((info == 0).all().item())}
+    out["f2_kriging_batched"] = dict(f2, workload="f2: gpvae_krig_predict_batched, S = 8000 hyper-parameter draws, 25 x 25 grid, f32; "
+                                                  "one workgroup per problem, Gram matrix / factor / inverse resident in LDS")
     # C3 again with the opt-in fp16 x 2 draw and factorisation (StepEngine(mfma="f16x2"): operands of the two
     # matrix products rounded to 22 bits, errors at the float32 level — tests/test_gpu_seams.py::test_h2_*,
     # test_potrf_h2_*): the same full training step as the headline, which stays on the operand-exact bf16 x 3

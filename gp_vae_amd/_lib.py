@@ -53,6 +53,7 @@ SIGNATURES = {
     "gpvae_krig_batched_workspace_bytes": (_i64, [_i, _i64, _i64, _i]),
     "gpvae_krig_predict_batched": (_i, [_vp, _i, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gpvae_krig_set_path": (None, [_i]),
     "gpvae_mvn_workspace_bytes": (_i64, [_i, _i64, _i]),
     "gpvae_mvn_logp": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp,
                             _vp]),

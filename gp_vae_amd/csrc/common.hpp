@@ -105,6 +105,77 @@ template <> struct Mfma16<double> {
   __device__ static __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
 
+// exp(-0.5 (sqrt(s) / ls)^2), the reference's order of operations (norm, divide, square, exp).
+// f32: with libm's sqrtf / IEEE division / expf the kernel is bound by the vector ALU at 2.6 TB/s
+// of stores (about 45 instructions per entry), not by HBM.  Here: v_sqrt_f32 (1 ulp), a multiply
+// by 1/ls, and exp as v_exp_f32 of x log2(e) with the product's rounding error carried along
+// (2^(hi+lo) = 2^hi (1 + lo ln 2)): 3 ulp on the entry, about 14 instructions.
+template <typename T> struct GramMath {
+  __device__ static __forceinline__ T expq(T s, T inv_ls) {
+    const T q = dsqrt<T>(s) * inv_ls;
+    return dexp<T>(T(-0.5) * (q * q));
+  }
+};
+template <> struct GramMath<float> {
+  __device__ static __forceinline__ float expq(float s, float inv_ls) {
+    const float q = __builtin_amdgcn_sqrtf(s) * inv_ls;
+    const float x = -0.5f * (q * q);
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E, -hi) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e, lo * 0.693147182464599609375f, e);
+  }
+};
+
+// 1/sqrt(x): v_rsq_f32 is accurate to 1 ulp; v_rsq_f64 is a ~26-bit seed refined by two Newton
+// steps.  Negative or NaN input gives NaN, zero gives +inf — both poison the column, as wanted.
+template <typename T> __device__ __forceinline__ T fast_rsqrt(T x);
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
+  return __builtin_amdgcn_rsqf(x);
+}
+template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-x * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+  }
+  return r;
+}
+
+// Pivot scaling with LAPACK-grade rounding.  Every entry of a column of L is scaled by the same
+// 1/L_jj, so an error in it is SYSTEMATIC: on a nearly rank-one matrix (long lengthscale,
+// K ~ var 11^T + jitter I) a 1-ulp bias in 1/sqrt(piv) perturbs the Schur complement by
+// 2 ulp * var * n in norm — at n = 300, jitter 1e-4, f32 that ate the whole margin and reported
+// "not positive definite" where LAPACK's spotrf succeeds.  Hence: L_jj = correctly rounded
+// sqrt(piv) (Newton on the v_rsq seed, Markstein correction), rd = its refined reciprocal, and
+// entries = correctly rounded s / L_jj (one fma correction of s * rd).
+// piv <= 0, NaN or 0 still poison the column (NaN / inf), as wanted.
+template <typename T> __device__ __forceinline__ void pivot_scale(T piv, T &ljj, T &rd) {
+  T y = fast_rsqrt<T>(piv);
+  const T e = fma(-(piv * y), y, T(1));
+  y = fma(T(0.5) * y, e, y);                 // 1/sqrt(piv), refined
+  const T l0 = piv * y;
+  ljj = fma(fma(-l0, l0, piv), T(0.5) * y, l0);  // sqrt(piv), correctly rounded
+  rd = fma(fma(-ljj, y, T(1)), y, y);        // 1/ljj
+}
+template <typename T> __device__ __forceinline__ T div_scaled(T s, T ljj, T rd) {
+  const T q = s * rd;
+  return fma(fma(-q, ljj, s), rd, q);  // s / ljj, correctly rounded (one correction step)
+}
+
+// value of lane j's v in every lane (v_readlane)
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int j);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
 // The scalar part of VAEInference.regression's potential (src/model/inference.py:243-254 in NumPyro's unconstrained
 // space), shared by vae_potential_kernel (vae.hip) and the fused NUTS iteration (nuts.hip) so that both evaluate it
 // with the very same operations: sq = sum of squared residuals at the observed columns, zz = |z|^2, u = log noise.

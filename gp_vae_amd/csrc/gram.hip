@@ -14,28 +14,7 @@ constexpr int GRAM_TX = 64;    // lanes along columns, 4 columns each => 256 col
 constexpr int GRAM_TY = 4;     // waves per block, one row each per iteration
 constexpr int GRAM_ROWS = 32;  // rows per block
 
-// exp(-0.5 (sqrt(s) / ls)^2), the reference's order of operations (norm, divide, square, exp).
-// f32: with libm's sqrtf / IEEE division / expf the kernel is bound by the vector ALU at 2.6 TB/s
-// of stores (about 45 instructions per entry), not by HBM.  Here: v_sqrt_f32 (1 ulp), a multiply
-// by 1/ls, and exp as v_exp_f32 of x log2(e) with the product's rounding error carried along
-// (2^(hi+lo) = 2^hi (1 + lo ln 2)): 3 ulp on the entry, about 14 instructions.
-template <typename T> struct GramMath {
-  __device__ static __forceinline__ T expq(T s, T inv_ls) {
-    const T q = dsqrt<T>(s) * inv_ls;
-    return dexp<T>(T(-0.5) * (q * q));
-  }
-};
-template <> struct GramMath<float> {
-  __device__ static __forceinline__ float expq(float s, float inv_ls) {
-    const float q = __builtin_amdgcn_sqrtf(s) * inv_ls;
-    const float x = -0.5f * (q * q);
-    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
-    const float hi = x * L2E;
-    const float lo = fmaf(x, L2E, -hi) + x * L2E_LO;
-    const float e = __builtin_amdgcn_exp2f(hi);
-    return fmaf(e, lo * 0.693147182464599609375f, e);
-  }
-};
+// GramMath<T>::expq (common.hpp): exp(-0.5 (sqrt(s) / ls)^2) in the reference's order of operations
 
 template <typename T, int D>
 __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(

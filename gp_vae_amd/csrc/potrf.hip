@@ -78,52 +78,8 @@ template <> struct PanelCfg<double> {
   static constexpr int S = 66;
 };
 
-template <typename T> __device__ __forceinline__ T lane_bcast(T v, int j);
-template <> __device__ __forceinline__ float lane_bcast<float>(float v, int j) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
-}
-template <> __device__ __forceinline__ double lane_bcast<double>(double v, int j) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(x): v_rsq_f32 is accurate to 1 ulp; v_rsq_f64 is a ~26-bit seed refined by two Newton
-// steps.  Negative or NaN input gives NaN, zero gives +inf — both poison the column, as wanted.
-template <typename T> __device__ __forceinline__ T fast_rsqrt(T x);
-template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
-  return __builtin_amdgcn_rsqf(x);
-}
-template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double e = fma(-x * r, r, 1.0);
-    r = fma(0.5 * r, e, r);
-  }
-  return r;
-}
-
-// Pivot scaling with LAPACK-grade rounding.  Every entry of a column of L is scaled by the same
-// 1/L_jj, so an error in it is SYSTEMATIC: on a nearly rank-one matrix (long lengthscale,
-// K ~ var 11^T + jitter I) a 1-ulp bias in 1/sqrt(piv) perturbs the Schur complement by
-// 2 ulp * var * n in norm — at n = 300, jitter 1e-4, f32 that ate the whole margin and reported
-// "not positive definite" where LAPACK's spotrf succeeds.  Hence: L_jj = correctly rounded
-// sqrt(piv) (Newton on the v_rsq seed, Markstein correction), rd = its refined reciprocal, and
-// entries = correctly rounded s / L_jj (one fma correction of s * rd).
-// piv <= 0, NaN or 0 still poison the column (NaN / inf), as wanted.
-template <typename T> __device__ __forceinline__ void pivot_scale(T piv, T &ljj, T &rd) {
-  T y = fast_rsqrt<T>(piv);
-  const T e = fma(-(piv * y), y, T(1));
-  y = fma(T(0.5) * y, e, y);                 // 1/sqrt(piv), refined
-  const T l0 = piv * y;
-  ljj = fma(fma(-l0, l0, piv), T(0.5) * y, l0);  // sqrt(piv), correctly rounded
-  rd = fma(fma(-ljj, y, T(1)), y, y);        // 1/ljj
-}
-template <typename T> __device__ __forceinline__ T div_scaled(T s, T ljj, T rd) {
-  const T q = s * rd;
-  return fma(fma(-q, ljj, s), rd, q);  // s / ljj, correctly rounded (one correction step)
-}
+// lane_bcast: common.hpp
+// fast_rsqrt / pivot_scale / div_scaled: common.hpp (shared with the small-problem kriging kernel)
 
 // ---- blocked (16-column windows) lane = row sweeps ---------------------------------------------------
 // A 64-step sweep costs 2016 dependent FMAs per lane.  Split into four 16-column windows it costs

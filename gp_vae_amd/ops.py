@@ -479,6 +479,12 @@ def krig_predict_batched(x_obs, x_test, y_obs, var, ls, sigma, jitter=1.0e-5, xi
     return mean, samp, vout, info
 
 
+def krig_set_path(force_big):
+    """True: gpvae_krig_predict_batched always takes the batched Gram + gpvae_potrf route; False (default): batches of
+    small problems run one workgroup per problem with everything in LDS.  For tests and benchmarks."""
+    _lib.load().gpvae_krig_set_path(1 if force_big else 0)
+
+
 # ---- a10 / f1: MVN log-density and gradient ---------------------------------------------------------
 def mvn_logp(x, f, var, ls, jitter=1.0e-5, grad=True):
     """log N(f_b; 0, K(x; var_b, ls_b) + jitter I) for a batch of chains, with d/df, d/dvar, d/dls.

@@ -254,6 +254,13 @@ int gpvae_krig_predict_batched(void *stream, int dtype, int d, int64_t n_obs, in
                                const void *var, const void *ls, const void *sigma, double jitter,
                                const void *xi, void *mean, void *sample, void *var_out,
                                int32_t *info, void *work);
+/* gpvae_krig_predict_batched takes one of two routes: batches of at least 8 problems with n_obs <= 160 (float32) /
+ * 96 (float64) run ONE WORKGROUP PER PROBLEM with the Gram matrix, its factor and the factor's inverse resident
+ * in LDS and the test points streamed through in tiles (what the reference's vmap over posterior draws asks
+ * for: inference.py:511-521, n_obs = 10..100 x thousands of draws; `work` is not touched on this route);
+ * everything else goes through the batched Gram + gpvae_potrf kernels.  gpvae_krig_set_path(1) forces the
+ * second route (tests and benchmarks compare the two), 0 restores the choice.  No counterpart in the reference. */
+void gpvae_krig_set_path(int force_big);
 
 /* ---- a10 / f1: MVN log-density with squared-exponential covariance, and its gradient ---------------
  * Replaces what NUTS differentiates in GPInference.gp_regression (src/model/inference.py:400-424):

@@ -758,3 +758,64 @@ def test_inference_fit_surface_with_nuts(ops):
     e_post = (post[:, obs].mean(0) - yo).abs().mean().item()
     e_prior = (prior[:, obs].mean(0) - yo).abs().mean().item()
     assert e_post < e_prior
+
+
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_kriging_batched_small_problems_in_lds(ops, ndt, tdt, tol):
+    """f2 as the reference uses it (vmap of gp_prediction over posterior draws, n_obs = 10..100: inference.py:511-521,
+    toy_examples.py:199): batches of small problems take the one-workgroup-per-problem route (Gram matrix, factor
+    and its inverse in LDS).  Against the oracle's literal arithmetic per draw and against the batched
+    Gram + gpvae_potrf route on the same inputs; every LDS tile size, ragged test tiles, the n_test == n_obs
+    jitter quirk, a non-PD problem in the middle of the batch, more problems than the chip holds at once."""
+    rng = np.random.default_rng(33)
+    f32 = ndt == np.float32
+    cases = [(1, 150, 37, 9), (2, 144, 100, 12), (1, 40, 20, 8), (2, 625, 10, 700), (1, 300, 64, 9), (1, 97, 96, 10)]
+    if f32:
+        cases += [(2, 625, 160, 9), (2, 400, 129, 8)]
+    for d, n, n_obs, S in cases:
+        g = int(round(n ** 0.5))
+        x = np.arange(n) / n if d == 1 else np.stack(np.meshgrid(np.arange(g) / g, np.arange(g) / g), -1).reshape(-1, 2)
+        obs = np.sort(rng.permutation(n)[:n_obs])
+        y = np.full(n, np.nan)
+        y[obs] = np.sin(5 * (x[obs] if d == 1 else x[obs].sum(1))) + 0.1 * rng.standard_normal(n_obs)
+        mask = np.ones(n, bool); mask[obs] = False
+        var = rng.uniform(0.5, 1.5, S); ls = rng.uniform(0.05, 0.3, S); sig = rng.uniform(0.01, 0.1, S)
+        bad = S // 2
+        sig[bad] = -10.0  # A = K + sigma I not positive definite
+        xi = rng.standard_normal((S, n - n_obs))
+        args = (dev(x[obs].astype(ndt), tdt), dev(x[mask].astype(ndt), tdt), dev(y[obs], tdt), var, ls, sig, 1e-5, dev(xi, tdt))
+        lib_ws = ops._lib.load().gpvae_krig_batched_workspace_bytes(0 if f32 else 1, n_obs, n - n_obs, S)
+        if n_obs <= (160 if f32 else 96):
+            assert lib_ws == 256, (n_obs, lib_ws)  # the LDS route takes no workspace
+        m, p, v, info = ops.krig_predict_batched(*args)
+        ops.krig_set_path(True)
+        try:
+            mb, pb, vb, infob = ops.krig_predict_batched(*args)
+        finally:
+            ops.krig_set_path(False)
+        info = info.cpu().numpy()
+        assert info[bad] > 0 and (np.delete(info, bad) == 0).all() and info[bad] == infob[bad].item()
+        assert np.isnan(m[bad].cpu().numpy()).all()
+        for s in sorted(set([0, 1, S - 1, min(S - 1, 300)]) - {bad}):
+            mo, po, vo = orc.gp_prediction(x, y, obs, var[s], ls[s], sig[s], xi[s])  # float64 truth
+            if not f32:
+                assert rel(m[s], mo) < 1e-7 and rel(p[s], po) < 1e-7 and rel(v[s], np.clip(vo, 0, None)) < 1e-6, (d, n_obs, s)
+            else:
+                f = np.float32
+                m32, p32, _ = orc.gp_prediction(x.astype(f), y.astype(f), obs, f(var[s]), f(ls[s]), f(sig[s]), xi[s].astype(f))
+                # the yard-stick: the worse of the oracle's own float32 run and the batched-kernel route
+                bar_m = f32_bar(max(rel(m32, mo), rel(mb[s], mo))); bar_p = f32_bar(max(rel(p32, po), rel(pb[s], po)))
+                assert rel(m[s], mo) < bar_m, (d, n_obs, s, rel(m[s], mo), rel(m32, mo), rel(mb[s], mo))
+                assert rel(p[s], po) < bar_p, (d, n_obs, s, rel(p[s], po), rel(p32, po), rel(pb[s], po))
+    # n_test == n_obs: the reference's kernel adds jitter to the (square) k_px too — inference.py:448 with gp.py:79-80
+    x = np.arange(40) / 40.0
+    obs = np.arange(0, 40, 2)
+    y = np.full(40, np.nan); y[obs] = np.cos(3 * x[obs])
+    mask = np.ones(40, bool); mask[obs] = False
+    S = 8
+    var = rng.uniform(0.5, 1.5, S); ls = rng.uniform(0.1, 0.3, S); sig = rng.uniform(0.05, 0.1, S)
+    m, p, v, info = ops.krig_predict_batched(dev(x[obs].astype(ndt), tdt), dev(x[mask].astype(ndt), tdt), dev(y[obs], tdt), var, ls, sig, 1e-2, None)
+    for s in (0, 7):
+        mo, po, vo = orc.gp_prediction(x, y, obs, var[s], ls[s], sig[s], None, 1e-2)
+        assert rel(m[s], mo) < (1e-9 if not f32 else 1e-4) and rel(v[s], np.clip(vo, 0, None)) < (1e-8 if not f32 else 1e-3)
+        assert torch.equal(m[s], p[s])  # no xi: the sample is the mean
