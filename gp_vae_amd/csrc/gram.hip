@@ -25,18 +25,27 @@ __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(
   const T var = var_p[b];
   const T inv_ls = T(1) / ls_p[b];
   T *Kb = K + (int64_t)b * strideK;
-  const int64_t j0 = ((int64_t)blockIdx.x * GRAM_TX + threadIdx.x) * 4;
+  // columns of this thread's four entries.  f32: four consecutive ones (one 16-byte store per lane, a wave writes
+  // 1 KB contiguously).  f64: two PAIRS, 128 columns apart, so that each of its two 16-byte stores is contiguous
+  // across the wave too — with four consecutive doubles per lane either store left every second 16 bytes of the
+  // cache lines it touched to the other one, and the builder ran at 3.0 TB/s whatever its arithmetic cost.
+  const int64_t jb = (int64_t)blockIdx.x * GRAM_TX * 4;
+  auto colof = [&](int c) -> int64_t {
+    if constexpr (sizeof(T) == 4) return jb + 4 * threadIdx.x + c;
+    else return jb + (c >> 1) * (2 * GRAM_TX) + 2 * threadIdx.x + (c & 1);
+  };
   const int64_t i0 = (int64_t)blockIdx.y * GRAM_ROWS;
-  if (j0 >= n_z) return;
+  if (colof(0) >= n_z) return;
 
   T zc[4][D];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const int64_t j = (j0 + c < n_z) ? j0 + c : n_z - 1;
+    const int64_t j = (colof(c) < n_z) ? colof(c) : n_z - 1;
 #pragma unroll
     for (int e = 0; e < D; ++e) zc[c][e] = z[j * D + e];
   }
-  const bool full = vec_ok && (j0 + 3 < n_z);
+  const bool full0 = vec_ok && (sizeof(T) == 4 ? colof(3) < n_z : colof(1) < n_z);
+  const bool full1 = vec_ok && colof(3) < n_z;  // f64: the second pair
 
   for (int r = threadIdx.y; r < GRAM_ROWS; r += GRAM_TY) {
     const int64_t i = i0 + r;
@@ -54,26 +63,34 @@ __global__ __launch_bounds__(GRAM_TX *GRAM_TY) void gram_se_kernel(
         s += dlt * dlt;
       }
       T k = var * GramMath<T>::expq(s, inv_ls);  // norm -> /ls -> square -> exp   gp.py:74-77
-      if (add_jitter && (i == j0 + c)) k += jitter;  // k += jitter*eye     gp.py:79-80
+      if (add_jitter && (i == colof(c))) k += jitter;  // k += jitter*eye     gp.py:79-80
       out[c] = k;
     }
-    T *dst = Kb + i * ldk + j0;
-    if (full) {
-      if constexpr (sizeof(T) == 4) {
-        // streaming store: the matrix is far larger than L2 and is read next by another launch
-        // (4.4 -> 5.9 TB/s; the f64 kernel is bound by its exp / sqrt and got slower with it)
+    T *row = Kb + i * ldk;
+    if constexpr (sizeof(T) == 4) {
+      if (full0) {
+        // streaming store: the matrix is far larger than L2 and is read next by another launch (4.4 -> 5.9 TB/s)
         typedef float vec4_t __attribute__((ext_vector_type(4)));
         vec4_t v = {out[0], out[1], out[2], out[3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<vec4_t *>(dst));
+        __builtin_nontemporal_store(v, reinterpret_cast<vec4_t *>(row + colof(0)));
       } else {
-        typename Vec4<T>::type v;
-        v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
-        *reinterpret_cast<typename Vec4<T>::type *>(dst) = v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (colof(c) < n_z) row[colof(c)] = out[c];
       }
     } else {
+      typedef double vec2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (j0 + c < n_z) dst[c] = out[c];
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0 ? full0 : full1) {
+          vec2_t v = {out[2 * h], out[2 * h + 1]};
+          __builtin_nontemporal_store(v, reinterpret_cast<vec2_t *>(row + colof(2 * h)));
+        } else {
+#pragma unroll
+          for (int c = 2 * h; c < 2 * h + 2; ++c)
+            if (colof(c) < n_z) row[colof(c)] = out[c];
+        }
+      }
     }
   }
 }
