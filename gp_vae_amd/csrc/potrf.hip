@@ -23,6 +23,11 @@ namespace gpvae {
 
 constexpr int NB = 64;     // inner (panel) block
 constexpr int NBO = 256;   // outer block
+// outer blocks per group of the delayed trailing update (bf16 x 3 path; potrf_syrk_b3_kernel).  Measured at batch
+// 16, f32 (ms, groups of 1 / 2 / 4): n = 1024: 0.560 / 0.570 / 0.592, 2048: 1.311 / 1.296 / 1.346,
+// 4096: 4.86 / 4.43 / 4.37 (batch 32: 8.62 / 7.64 / 7.50) — the narrow launches of a group fill the chip only
+// when the matrix is tall
+static inline int b3_group(int64_t n) { return n >= 16 * NBO ? 4 : (n >= 8 * NBO ? 2 : 1); }
 
 // developer probe (make DEV=1 builds only): when set (gpvae_dev_set_stamps), block (0,0) of the panel
 // launch of column block c0/64 writes s_memtime at its phase boundaries to stamps[8*(c0/64) + 0..7].
@@ -52,8 +57,8 @@ template <typename T> struct VRows {
 
 // Where the bf16 planes of the factor's columns go (float32 problems on the bf16 x 3 path): piece pl of
 // element (vrow, col) of matrix b at  p[b*stride + pl*plane + vrow*ld + col - coloff].
-//   workspace mode (gpvae_potrf): only the current outer panel, [row][256], coloff = cJ, rows below
-//     the outer block only (first_row = cJ + 256);
+//   workspace mode (gpvae_potrf): only the current GROUP of outer panels (b3_group(n) of them), [row][256 D],
+//     coloff = col0 = first column of the group, rows below the outer block being factored only;
 //   factor mode (gpvae_potrf_b3): the caller's whole L3 [n][ld3], coloff = 0, every row.
 // np = 2 (gpvae_potrf_h2): two fp16 planes of the factor TIMES scale[b] (a power of two chosen from the largest
 // diagonal entry of matrix b: |L_ij| <= sqrt(max K_ii)), same addressing (two-byte elements either way).
@@ -63,6 +68,7 @@ struct B3Out {
   int whole;           // factor mode
   int np;              // planes per operand: 3 (bf16) or 2 (fp16)
   const float *scale;  // np == 2: per matrix
+  int64_t col0 = 0;    // matrix column held in plane column 0 (workspace mode: first column of the block pair)
 };
 
 template <typename T> struct PanelCfg;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
       // rows below the outer block also go out as three bf16 planes [plane][row][256]: the operand of
       // the bf16 x 3 trailing update (potrf_syrk_b3_kernel), pieces summing to the float exactly
       if (o3.p != nullptr && (o3.whole || rbase + s >= cJ + NBO)) {
-        __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (o3.whole ? c0 : c0 - cJ) + j;
+        __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (c0 - o3.col0) + j;
         if (o3.np == 2) {
           const float sc = o3.scale[b];
           _Float16 hh[4], ll[4];
@@ -601,9 +607,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
 // 256 x 128 tiles, one workgroup per CU.  The accumulators start from -C as above.  Tiles that cross
 // the diagonal (tc >= 2 tr) compute their upper part too and mask it in the store.
 // Tile p of a matrix -> (tr, tc), tc <= 2 tr + 1: row tr holds 2 tr + 2 tiles.
+// Delayed update: the outer blocks go in groups of D = b3_group(n).  After a block inside a group only the NEXT
+// 256 columns are updated (narrow map), with every column of the group so far (K = 256, 512, ...); after the
+// group's last block everything right of it with K = 256 D — the same products accumulated in the same order
+// (f32 accumulators stored and reloaded between launches lose nothing: the factor is bit-identical to D = 1),
+// but a tile's C load, pipeline fill and store (~6 us) are paid per 8 D k-tiles instead of per 8.
 struct SyrkB3Map {
   int R, batch;   // 256-row tile rows of the trailing matrix
-  int64_t per;    // R (R + 1) tiles per matrix
+  int64_t per;    // R (R + 1) tiles per matrix; narrow (the first 256 columns only): 2 R
+  int narrow;
   __host__ int64_t grid() const {
     return batch >= 8 ? 8 * (int64_t)((batch + 7) / 8) * per : (int64_t)batch * per;
   }
@@ -620,6 +632,11 @@ struct SyrkB3Map {
       b = (int)(id / per);
       p = id - (int64_t)b * per;
     }
+    if (narrow) {
+      tr = (int)(p >> 1);
+      tc = (int)(p & 1);
+      return true;
+    }
     int r = (int)((sqrtf(4.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
     while ((int64_t)r * (r + 1) > p) --r;
     while ((int64_t)(r + 1) * (r + 2) <= p) ++r;
@@ -634,7 +651,7 @@ struct SyrkB3Map {
 template <int NP>
 __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
                                                                     int64_t strideA, B3Out o3,
-                                                                    int64_t cJ, int64_t kend,
+                                                                    int64_t cP, int K, int64_t kend,
                                                                     SyrkB3Map map) {
   using M = Mfma<float>;
   using PipeB3 = PipeB3T<4, NP>;
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
   if (!map.decode(blockIdx.x, b, tr, tc)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *Ab = A + (int64_t)b * strideA;
-  const __bf16 *Pb = o3.p + (int64_t)b * o3.stride + (o3.whole ? cJ : 0);  // row 0, first panel column
+  const __bf16 *Pb = o3.p + (int64_t)b * o3.stride + (cP - o3.col0);  // row 0, first column of the K panel columns
   const int64_t r0 = kend + (int64_t)tr * B3_TM, q0 = kend + (int64_t)tc * B3_TN;
   const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
   PipeB3 P;
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] *= s2;
   }
-  P.run(lds, 0, NBO);
+  P.run(lds, 0, K);
   if constexpr (NP == 2) {
     const float is = 1.0f / o3.scale[b], is2 = is * is;
 #pragma unroll
@@ -815,7 +832,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
   B3Out o3{nullptr, 0, 0, 0, 0};
   if (b3) {
     if (ext.p != nullptr) o3 = ext;  // the caller's whole-factor planes double as the panel operand
-    else o3 = B3Out{(__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)), NBO, vr.npad * NBO, 3 * vr.npad * NBO, 0, 3, nullptr};
+    else o3 = B3Out{(__bf16 *)((char *)work + l11_bytes(sizeof(T), n, batch)), b3_group(n) * NBO, vr.npad * b3_group(n) * NBO, 3 * vr.npad * b3_group(n) * NBO, 0, 3, nullptr};
   } else if (ext.p != nullptr) {
     set_error("gpvae_potrf_b3: needs 16-byte aligned rows (lda %% 4 == 0) and 128*lda*4 < 2^31");
     return -5;
@@ -824,8 +841,12 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     set_error("gpvae_potrf: hipMemsetAsync(info) failed");
     return -12;
   }
+  const int D = b3_group(n);
   for (int64_t cJ = 0; cJ < n; cJ += NBO) {
     const int64_t kend = (cJ + NBO < n) ? cJ + NBO : n;
+    const int jj = (int)((cJ / NBO) % D);          // position in the group of D outer blocks (b3 path)
+    const int64_t cP = cJ - (int64_t)jj * NBO;     // first column of the group
+    if (b3 && !o3.whole) o3.col0 = cP;
     for (int64_t c0 = cJ; c0 < kend; c0 += NB) {
       const int64_t below = Mv - (c0 + NB);
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
@@ -836,13 +857,17 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     if constexpr (sizeof(T) == 4) {
       if (b3 && kend < n) {
         const int R = (int)((n - kend) / B3_TM);
-        const SyrkB3Map map{R, batch, (int64_t)R * (R + 1)};
+        // inside a group: the next 256 columns only, with every column of the group so far (with one block
+        // left that is the whole update); after its last block: everything right of the group
+        const bool narrow = jj + 1 < D && R > 1;
+        const SyrkB3Map map{R, batch, narrow ? 2 * (int64_t)R : (int64_t)R * (R + 1), narrow ? 1 : 0};
+        const int K = (jj + 1) * NBO;
         if (o3.np == 2)
           hipLaunchKernelGGL(potrf_syrk_b3_kernel<2>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                             lda, strideA, o3, cJ, kend, map);
+                             lda, strideA, o3, cP, K, kend, map);
         else
           hipLaunchKernelGGL(potrf_syrk_b3_kernel<3>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                             lda, strideA, o3, cJ, kend, map);
+                             lda, strideA, o3, cP, K, kend, map);
         continue;
       }
     }
@@ -887,11 +912,11 @@ extern "C" int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_e
   // one dense 64x64 block per diagonal block and matrix: the factored diagonal blocks wait here
   // until the last launch copies them over A (see potrf_panel_kernel's store phase)
   // ... and, for float32 problems that take the bf16 x 3 trailing update (n a multiple of 256, no extra
-  // rows), the current outer panel as three bf16 planes: batch * 3 * n * 256 * 2 bytes
+  // rows), the current group of outer panels as three bf16 planes: batch * 3 * n * 256 b3_group(n) * 2 bytes
   if (n <= 0 || batch <= 0) return 0;
   const int64_t es = dtype == GPVAE_F64 ? 8 : 4;
   int64_t bytes = l11_bytes(es, n, batch);
-  if (potrf_b3_ok(dtype == GPVAE_F32, n, m_extra)) bytes += (int64_t)batch * 3 * round_up(n, NB) * NBO * 2;
+  if (potrf_b3_ok(dtype == GPVAE_F32, n, m_extra)) bytes += (int64_t)batch * 3 * round_up(n, NB) * b3_group(n) * NBO * 2;
   return bytes;
 }
 
@@ -918,7 +943,7 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
     const int rt = (int)cdiv(round_up(n, NB) + m_extra, SBM), ct = (int)cdiv(n, SBM);
     const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 4, "gpvae_potrf: batch x tiles exceeds one launch; split the batch");
-    GPVAE_REQUIRE((int64_t)batch * 3 * round_up(n, NB) * NBO < ((int64_t)1 << 40), 4, "gpvae_potrf: batch too large");
+    GPVAE_REQUIRE((int64_t)batch * 3 * round_up(n, NB) * b3_group(n) * NBO < ((int64_t)1 << 40), 4, "gpvae_potrf: batch too large");
   }
   hipStream_t st = (hipStream_t)stream;
   if (m_extra == 0) X = nullptr;

@@ -32,8 +32,8 @@ extern "C" {
 #endif
 
 /* 2: workspace contents changed (round 2): gpvae_potrf_workspace_bytes also covers the bf16 planes of the
- * current 256-column panel (float32, n % 256 == 0, n >= 512, m_extra == 0: trailing updates on the bf16 matrix
- * pipe), decoder / mvn workspaces hold per-slice slabs instead of atomically accumulated buffers.  A caller must
+ * current 256-column panels (float32, n % 256 == 0, n >= 512, m_extra == 0: trailing updates on the bf16 matrix
+ * pipe; a group of up to four panels since round 3 — the query says how much), decoder / mvn workspaces hold per-slice slabs instead of atomically accumulated buffers.  A caller must
  * size every workspace with the *_workspace_bytes query of the library it runs against. */
 #define GPVAE_ABI_VERSION 2
 
@@ -79,11 +79,13 @@ int gpvae_gram_agg(void *stream, int dtype, int d, int64_t n_cells, int m, const
  * info[b] (int32): 0 = ok, j>0 = leading minor j not positive definite (LAPACK potrf).
  * work: gpvae_potrf_workspace_bytes() bytes, 16-byte aligned.  Contents: the factored diagonal blocks,
  * parked there until the last launch (late workgroups of a panel launch never see a half-updated A),
- * and — float32 with n % 256 == 0, n >= 512 and m_extra == 0 — behind them batch * 3 * n * 256 bf16
- * values: the current 256-column panel as three bf16 planes (exact 8+8+8-bit split of every float).
- * On that route the trailing updates C -= P P^T run on the bf16 matrix pipe from those planes (six
- * piece products per float product, f32 accumulation: float32-accurate, csrc/b3.hpp); every other
- * shape and dtype uses the f32 / f64 MFMA.  Always size `work` with the query below.                 */
+ * and — float32 with n % 256 == 0, n >= 512 and m_extra == 0 — behind them batch * 3 * n * 256 g bf16
+ * values: the current group of g 256-column panels as three bf16 planes (exact 8+8+8-bit split of every
+ * float; g = 1 below n = 2048, 2 below 4096, else 4).  On that route the trailing updates C -= P P^T run on
+ * the bf16 matrix pipe from those planes (six piece products per float product, f32 accumulation:
+ * float32-accurate, csrc/b3.hpp), delayed so that all columns right of a group are updated once per group
+ * with K = 256 g (same sums in the same order: bit-identical to g = 1); every other shape and dtype uses
+ * the f32 / f64 MFMA.  Always size `work` with the query below.                                       */
 int64_t gpvae_potrf_workspace_bytes(int dtype, int64_t n, int64_t m_extra, int batch);
 int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *A, int64_t lda,
                 int64_t strideA, int64_t m_extra, void *X, int64_t ldx, int64_t strideX,

@@ -389,7 +389,8 @@ def test_potrf_b3_factor_and_planes():
     rng = np.random.default_rng(5)
     assert ops.potrf_b3_supported(4096) and ops.potrf_b3_supported(512) and not ops.potrf_b3_supported(300) \
         and not ops.potrf_b3_supported(256)
-    for n, batch in ((512, 3), (1280, 9)):
+    # 2304 / 4352: 9 / 17 outer blocks — the trailing updates delayed over groups of 2 / 4 blocks, the last group short
+    for n, batch in ((512, 3), (1280, 9), (2304, 3), (4352, 3)):
         x = torch.tensor(rng.random((n, 2)), dtype=torch.float32, device=DEV)
         ls = torch.linspace(0.05, 0.6, batch, device=DEV)
         K = ops.gram_se(x, x, torch.ones(batch, device=DEV), ls, 1e-3).reshape(batch, n, n)
@@ -410,7 +411,8 @@ def test_potrf_b3_factor_and_planes():
             E3 = ops.randn_b3((256, n), DEV, seed=b, stream_id=2)
             want = ops.draw_b3(ops.split_b3(A[b], lower=True), E3)
             assert torch.equal(ops.draw_b3(L3[b], E3), want)
-            assert rel(A[b].tril(), ref[b].tril().cpu().numpy()) < 1e-6  # same factor as the plain entry point
+            # the plain entry point (planes of the current group of panels in its workspace) does the same arithmetic
+            assert torch.equal(A[b].tril(), ref[b].tril())
         # NaN-on-fail: every draw from a failed matrix's planes is NaN
         A2 = K.clone()
         info2, L32 = ops.potrf_b3_(A2, nan_on_fail=True)
