@@ -6,7 +6,9 @@
 //
 // Two-level blocking, two kernels, no inter-workgroup hand-off inside a launch:
 //   outer block NBO = 256 columns, right-looking:  potrf_syrk_kernel  C -= P P^T   (MFMA, K = 256;
-//       >= 89 % of the flops at n = 4096; 128x128 tiles => 128 flop/byte of C traffic in f32)
+//       >= 89 % of the flops at n = 4096; 128x128 tiles => 128 flop/byte of C traffic in f32).  On tall
+//       matrices the update is delayed over groups of outer blocks (b3_group / mfma_group below): inside a
+//       group only the next 256 columns are brought up to date, after it everything right of it with K = 256 g
 //   inner block NB = 64 columns, left-looking inside the outer block: potrf_panel_kernel, ONE launch
 //       per 64 columns.  Every workgroup (a) applies the outer block's earlier columns to the 64x64
 //       diagonal block and to its own 64-row chunks with MFMA, (b) factors the diagonal block in LDS
@@ -27,6 +29,9 @@ constexpr int NBO = 256;   // outer block
 // 16, f32 (ms, groups of 1 / 2 / 4): n = 1024: 0.560 / 0.570 / 0.592, 2048: 1.311 / 1.296 / 1.346,
 // 4096: 4.86 / 4.43 / 4.37 (batch 32: 8.62 / 7.64 / 7.50) — the narrow launches of a group fill the chip only
 // when the matrix is tall
+// the same on the f32 / f64 MFMA trailing update (potrf_syrk_kernel; groups of 1 / 2 / 4): f64 16 x 4096 10.25 / 9.68 /
+// 9.88 ms, f64 16 x 2048 2.24 / 2.22 / 2.40, f32 16 x 4000 5.61 / 5.30 / 5.39, f64 2 x 8192 12.1 / 11.9 / 12.4
+static inline int mfma_group(int64_t n) { return n >= 15 * NBO ? 2 : 1; }
 static inline int b3_group(int64_t n) { return n >= 16 * NBO ? 4 : (n >= 8 * NBO ? 2 : 1); }
 
 // developer probe (make DEV=1 builds only): when set (gpvae_dev_set_stamps), block (0,0) of the panel
@@ -477,7 +482,8 @@ constexpr int SBM = 128;
 
 struct SyrkMap {
   int rt, ct, batch;
-  int64_t per;  // tiles per matrix
+  int64_t per;  // tiles per matrix; narrow (the first two tile columns only): 2 rt - 1
+  int narrow;
   __host__ __device__ static int64_t tiles(int rt, int ct) {
     return (int64_t)ct * (ct + 1) / 2 + (int64_t)(rt - ct) * ct;
   }
@@ -498,6 +504,11 @@ struct SyrkMap {
       b = (int)(id / per);
       p = id - (int64_t)b * per;
     }
+    if (narrow) {
+      tr = (int)((p + 1) >> 1);  // (0,0), (1,0), (1,1), (2,0), (2,1), ...
+      tc = p == 0 ? 0 : (int)((p + 1) & 1);
+      return true;
+    }
     const int64_t ntri = (int64_t)ct * (ct + 1) / 2;
     if (p < ntri) {
       int r = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
@@ -516,7 +527,7 @@ struct SyrkMap {
 
 template <typename T, bool VECM>
 __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
-    VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cJ, int64_t kend, SyrkMap map) {
+    VRows<T> vr, int64_t strideA, int64_t strideX, int64_t cP, int64_t kend, SyrkMap map) {
   using M = Mfma<T>;
   constexpr int SBK = TileK<T>::BK;
   constexpr int F = 64 / M::TM;  // MFMA tiles per wave edge
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
   // in a diagonal tile the wave at (0,1) only holds entries above the diagonal: it stages operands
   // and keeps the barriers but issues no MFMA
   const bool wanted = !(diag_tile && wm == 0 && wn == 64);
-  pipe.run(la, lb, lds, cJ, kend, wm, wn, lane, tid, acc, wanted);
+  pipe.run(la, lb, lds, cP, kend, wm, wn, lane, tid, acc, wanted);
   if (!wanted) return;
   if (interior) {
 #pragma unroll
@@ -841,7 +852,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     set_error("gpvae_potrf: hipMemsetAsync(info) failed");
     return -12;
   }
-  const int D = b3_group(n);
+  const int D = b3 ? b3_group(n) : mfma_group(n);
   for (int64_t cJ = 0; cJ < n; cJ += NBO) {
     const int64_t kend = (cJ + NBO < n) ? cJ + NBO : n;
     const int jj = (int)((cJ / NBO) % D);          // position in the group of D outer blocks (b3 path)
@@ -873,9 +884,10 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     }
     if (kend < n) {
       const int rt = (int)cdiv(Mv - kend, SBM), ct = (int)cdiv(n - kend, SBM);
-      const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+      const bool narrow = jj + 1 < D && ct > 2;  // as on the bf16 x 3 path: the next 256 columns only
+      const SyrkMap map{rt, ct, batch, narrow ? 2 * (int64_t)rt - 1 : SyrkMap::tiles(rt, ct), narrow ? 1 : 0};
       hipLaunchKernelGGL((potrf_syrk_kernel<T, VECM>), dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st,
-                         vr, strideA, strideX, cJ, kend, map);
+                         vr, strideA, strideX, cP, kend, map);
     }
   }
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
@@ -941,7 +953,7 @@ extern "C" int gpvae_potrf(void *stream, int dtype, int64_t n, int batch, void *
                 "gpvae_potrf: work is NULL or not 16-byte aligned (gpvae_potrf_workspace_bytes)");
   {  // the trailing update is one 1-D launch over all tiles of all matrices
     const int rt = (int)cdiv(round_up(n, NB) + m_extra, SBM), ct = (int)cdiv(n, SBM);
-    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct), 0};
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 4, "gpvae_potrf: batch x tiles exceeds one launch; split the batch");
     GPVAE_REQUIRE((int64_t)batch * 3 * round_up(n, NB) * b3_group(n) * NBO < ((int64_t)1 << 40), 4, "gpvae_potrf: batch too large");
   }
@@ -983,7 +995,7 @@ extern "C" int gpvae_potrf_b3(void *stream, int64_t n, int batch, void *A, int64
   GPVAE_REQUIRE(PipeB3::usable(ld3, ld3), 11, "gpvae_potrf_b3: ld3 too large");
   {
     const int rt = (int)cdiv(round_up(n, NB), SBM), ct = (int)cdiv(n, SBM);
-    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct), 0};
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 3, "gpvae_potrf_b3: batch x tiles exceeds one launch; split the batch");
   }
   return run_potrf<float>((hipStream_t)stream, n, batch, A, lda, strideA, 0, nullptr, 0, 0, info, flags, work,
@@ -1017,7 +1029,7 @@ extern "C" int gpvae_potrf_h2(void *stream, int64_t n, int batch, void *A, int64
   GPVAE_REQUIRE((PipeB3T<4, 2>::usable(ld2, ld2)), 11, "gpvae_potrf_h2: ld2 too large");
   {
     const int rt = (int)cdiv(round_up(n, NB), SBM), ct = (int)cdiv(n, SBM);
-    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct)};
+    const SyrkMap map{rt, ct, batch, SyrkMap::tiles(rt, ct), 0};
     GPVAE_REQUIRE(map.grid() <= 0x7fffffffLL, 3, "gpvae_potrf_h2: batch x tiles exceeds one launch; split the batch");
   }
   float *scale = (float *)((char *)work + l11_bytes(4, n, batch));

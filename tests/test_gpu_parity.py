@@ -203,6 +203,37 @@ def test_potrf_tile_map_batches(ops, batch):
         assert rel(A[b], L) < 1e-12 and rel(Xd[b], orc.right_solve_lt(L, X[b])) < 1e-11
 
 
+@pytest.mark.parametrize("ndt,tdt,tol", DTYPES)
+def test_potrf_delayed_trailing_update_ragged_with_extra_rows(ops, ndt, tdt, tol):
+    """From 15 outer blocks up the trailing update is delayed over pairs of outer blocks (potrf.hip mfma_group):
+    inside a pair only the next 256 columns are brought up to date (the narrow tile map), after it everything
+    right of it with K = 512.  Ragged n (a partial last outer block and 128-tile) with extra rows, whose tiles
+    sit in the narrow map too, batch on both sides of the 8-matrix XCD switch."""
+    rng = np.random.default_rng(77)
+    n, m = 3900, 200
+    x = rng.random((n, 2))
+    for batch in (2, 9):
+        ls = np.linspace(0.08, 0.5, batch)
+        K = np.stack([orc.exp_kernel2(x, x, 1.0, l, 1e-3) for l in ls]).astype(ndt)
+        X = rng.standard_normal((batch, m, n)).astype(ndt)
+        A, Xd = dev(K, tdt), dev(X, tdt)
+        info = ops.potrf_(A, Xd)
+        assert info.cpu().tolist() == [0] * batch
+        for b in (0, batch - 1):
+            L64 = np.linalg.cholesky(K[b].astype(np.float64))
+            Lg = A[b].cpu().numpy().astype(np.float64)
+            Kb = K[b].astype(np.float64)
+            bw = np.linalg.norm(Lg @ Lg.T - Kb) / np.linalg.norm(Kb)
+            assert bw < (1e-14 if ndt == np.float64 else 2e-6), bw
+            want = orc.right_solve_lt(L64, X[b].astype(np.float64))
+            if ndt == np.float64:
+                t = ts = 1e-9
+            else:  # what LAPACK's float32 spotrf + the same solve lose on these inputs
+                Lf = orc.cholesky_lower(K[b])
+                t, ts = f32_bar(rel(Lf, L64)), f32_bar(rel(orc.right_solve_lt(Lf, X[b]), want))
+            assert rel(Lg, L64) < t and rel(Xd[b], want) < ts
+
+
 def test_potrf_overlapped_sub_batches(ops):
     """The sub-batch / side-stream form gives the factors and info values of the plain call."""
     rng = np.random.default_rng(31)
