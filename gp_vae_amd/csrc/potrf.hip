@@ -63,7 +63,7 @@ template <typename T> struct VRows {
 // Where the bf16 planes of the factor's columns go (float32 problems on the bf16 x 3 path): piece pl of
 // element (vrow, col) of matrix b at  p[b*stride + pl*plane + vrow*ld + col - coloff].
 //   workspace mode (gpvae_potrf): only the current GROUP of outer panels (b3_group(n) of them), [row][256 D],
-//     coloff = col0 = first column of the group, rows below the outer block being factored only;
+//     coloff = col0 = first column of the group;
 //   factor mode (gpvae_potrf_b3): the caller's whole L3 [n][ld3], coloff = 0, every row.
 // np = 2 (gpvae_potrf_h2): two fp16 planes of the factor TIMES scale[b] (a power of two chosen from the largest
 // diagonal entry of matrix b: |L_ij| <= sqrt(max K_ii)), same addressing (two-byte elements either way).
@@ -242,8 +242,113 @@ __device__ __forceinline__ int window16(T *img, T *Dm, T *rdiag, int W, int lane
   return fail;
 }
 
-template <typename T, bool VECM>
-__global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
+// ---- the panel's left-looking update on the bf16 matrix pipe (float32 problems whose rows exist as planes) ----
+// [D; C] -= [Pd; Pc] Pd^T over the columns [cJ, c0) the outer block has factored so far, read as the planes the
+// earlier panel launches of this block wrote (b3.hpp: three bf16 pieces, six piece products; NP = 2: two fp16
+// pieces of L * scale, three products).  The f32 MFMA version of this update was 0.8 of the 2.1 ms the 64 panel
+// launches of a 16 x 4096 factorisation take (10 / 17 / 24 us of the second / third / fourth launch of a block).
+// Per block of 64 columns: the diagonal rows' planes (the B operand of every product, and both operands of the
+// wave's quadrant of D) are staged in LDS once per workgroup — [plane][8-k chunk][row][16 B], the conflict-free
+// fragment image of PipeB3 — while every wave loads the fragments of its own 32 chunk rows straight from global
+// memory, 16 bytes per lane = the 8 k values of a 32x32x16 operand row, four k16 steps ahead in a ring of
+// registers.  (All nine fragments per step straight from global memory was tried first: a CU issues one 16-byte
+// wave load per ~29 cycles whatever its pattern — tools/ub_vmem.hip — and 72 per step and CU took twice the
+// MFMA time: 4.86 against 4.46 ms per 16 x 4096.)
+template <int NP> struct PanelB3 {
+  static constexpr int CP = 64 * 16 + 32;              // bytes per (plane, chunk) image: 64 rows x 16 B + pad
+  static constexpr int LDS_BYTES = NP * 8 * CP;        // one block of 64 columns: 25.3 KB (NP = 3)
+  static constexpr int NST = NP * 64 * 8 / NTHREADS;   // 16-byte pieces per thread and block: 6 (4)
+  i32x4_t ringA[4][NP];   // [k16 step of the block][plane]: the wave's own rows
+  i32x4_t st[NST];        // staging registers: piece i = plane i / 2, diagonal row tid / 8 + 32 (i % 2), chunk tid % 8
+  i32x4_t fb[2][NP][2];   // fragments of the two 32-row tiles of the diagonal rows: this k16 step's and the next one's
+  const char *pa, *pd;    // the lane's own row / the thread's staging row and chunk, at column cJ
+  int64_t plane2, ld32;   // bytes between planes / between 32 rows
+  int wr, rd;             // LDS byte offsets: staging write, fragment read
+
+  __device__ __forceinline__ void init(const B3Out &o3, int b, int64_t row_a, int64_t row_d, int64_t cJ, int tid) {
+    const int lane = tid & 63;
+    const __bf16 *base = o3.p + (int64_t)b * o3.stride + (cJ - o3.col0);
+    pa = reinterpret_cast<const char *>(base + (row_a + (lane & 31)) * o3.ld + (lane >> 5) * 8);
+    pd = reinterpret_cast<const char *>(base + (row_d + (tid >> 3)) * o3.ld + (tid & 7) * 8);
+    plane2 = o3.plane * 2;
+    ld32 = o3.ld * 64;
+    wr = (tid & 7) * CP + (tid >> 3) * 16;
+    rd = (lane >> 5) * CP + (lane & 31) * 16;
+  }
+  template <int STEP> __device__ __forceinline__ void load_a(int blk) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      ringA[STEP][p] = *reinterpret_cast<const i32x4_t *>(pa + p * plane2 + blk * 128 + STEP * 32);
+  }
+  __device__ __forceinline__ void stage_load(int blk) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      st[i] = *reinterpret_cast<const i32x4_t *>(pd + (i >> 1) * plane2 + (i & 1) * ld32 + blk * 128);
+  }
+  __device__ __forceinline__ void stage_store(unsigned char *lds) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      *reinterpret_cast<i32x4_t *>(lds + wr + (i >> 1) * 8 * CP + (i & 1) * 512) = st[i];
+  }
+  template <int STEP> __device__ __forceinline__ void read_b(const unsigned char *lds) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        fb[STEP & 1][p][t] = *reinterpret_cast<const i32x4_t *>(lds + rd + (p * 8 + 2 * STEP) * CP + t * 512);
+  }
+  __device__ __forceinline__ static f32x16 mfma(const i32x4_t &x, const i32x4_t &y, const f32x16 &c) {
+    if constexpr (NP == 3)
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, x), __builtin_bit_cast(f16x8_t, y), c, 0, 0, 0);
+  }
+  // accC[fn] += Pc Pd(32 fn ..)^T ; accD += Pd(32 di ..) Pd(32 dj ..)^T, smallest piece products first.
+  // di, dj MUST be scalar values (readfirstlane): an MFMA does not honour EXEC, so a quadrant choice the compiler
+  // takes for divergent runs all four products into accD.
+  template <int STEP>
+  __device__ __forceinline__ void mma(f32x16 (&accC)[2], f32x16 &accD, int di, int dj) {
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};  // NP == 3
+    constexpr int QA[3] = {0, 1, 0}, QB[3] = {1, 0, 0};                    // NP == 2
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+    for (int q = 0; q < NPROD; ++q) {
+      const int a = NP == 3 ? PA[q] : QA[q], bq = NP == 3 ? PB[q] : QB[q];
+      constexpr int F = STEP & 1;
+      accC[0] = mfma(ringA[STEP][a], fb[F][bq][0], accC[0]);
+      accC[1] = mfma(ringA[STEP][a], fb[F][bq][1], accC[1]);
+      if (di == 0 && dj == 0) accD = mfma(fb[F][a][0], fb[F][bq][0], accD);
+      else if (di == 0) accD = mfma(fb[F][a][0], fb[F][bq][1], accD);
+      else if (dj == 0) accD = mfma(fb[F][a][1], fb[F][bq][0], accD);
+      else accD = mfma(fb[F][a][1], fb[F][bq][1], accD);
+    }
+  }
+  // first requests, ahead of the barrier that ends the copy-in
+  __device__ __forceinline__ void prologue() {
+    stage_load(0);
+    load_a<0>(0); load_a<1>(0); load_a<2>(0); load_a<3>(0);
+  }
+  // nblk blocks of four k16 steps (64 columns each); two barriers per block
+  __device__ __forceinline__ void run(unsigned char *lds, int nblk, f32x16 (&accC)[2], f32x16 &accD, int di, int dj) {
+    for (int blk = 0; blk < nblk; ++blk) {
+      const bool more = blk + 1 < nblk;
+      stage_store(lds);
+      __syncthreads();
+      if (more) stage_load(blk + 1);
+      read_b<0>(lds);
+      read_b<1>(lds); mma<0>(accC, accD, di, dj); if (more) load_a<0>(blk + 1);
+      read_b<2>(lds); mma<1>(accC, accD, di, dj); if (more) load_a<1>(blk + 1);
+      read_b<3>(lds); mma<2>(accC, accD, di, dj); if (more) load_a<2>(blk + 1);
+      mma<3>(accC, accD, di, dj); if (more) load_a<3>(blk + 1);
+      __syncthreads();  // every wave has read this block's image
+    }
+  }
+};
+
+// NPL = 3 / 2: the rows exist as bf16 / fp16 planes (B3Out) and the left-looking update runs on them (float32
+// only); NPL = 0: the update on the f32 / f64 MFMA from A itself
+template <typename T, bool VECM, int NPL>
+__global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, T *dwork,
                                                                B3Out o3,
@@ -282,6 +387,17 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   const int dm0 = (M::TM == 32) ? (wave >> 1) * 32 : wave * 16;
   const int dn0 = (M::TM == 32) ? (wave & 1) * 32 : 0;
   const bool vcols = VECM && (c0 + NB <= n);  // the 64 columns are whole and 16-byte aligned
+
+  // planes route: the first block of plane fragments is requested ahead of the copy-in (both latencies together)
+  constexpr bool PL = NPL != 0;
+  PanelB3<PL ? NPL : 3> pl;
+  if constexpr (PL) {
+    if (c0 > cJ) {
+      const int64_t row_a = rbase + wave * 32;  // rows past n (second chunk of the last workgroup) are never stored:
+      pl.init(o3, b, row_a + 31 < n ? row_a : n - 32, c0, cJ, tid);  // read real rows instead
+      pl.prologue();
+    }
+  }
 
   // ---- copy [D; C] (columns c0..c0+63 of the stacked rows) global -> LDS, 16 bytes per lane ------
   // branch-free (clamped pointer + select) so every load is in flight at once
@@ -329,7 +445,41 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
   }
 
   // ---- (a) apply columns [cJ, c0) of the outer block: [D; C] -= [Pd; Pc] Pd^T ------------------
-  if (c0 > cJ) {
+  if constexpr (PL) {
+    static_assert(sizeof(T) == 4 && VECM, "planes: float32 with 16-byte aligned rows");
+    if (c0 > cJ) {  // the bf16 x 3 / fp16 x 2 route: these rows exist as planes (PanelB3 above)
+      const int nblk = (int)((c0 - cJ) / NB);
+      // scalar values: the quadrant branches of PanelB3::mma must be real branches (an MFMA does not honour EXEC)
+      const int wu = __builtin_amdgcn_readfirstlane(wave);
+      const int di = wu >> 1, dj = wu & 1;
+      __shared__ __align__(16) unsigned char pst[PanelB3<PL ? NPL : 3>::LDS_BYTES];
+      float sc2 = 1.0f, isc2 = 1.0f;  // fp16 x 2: the planes hold L * scale
+      if constexpr (NPL == 2) {
+        const float sc = o3.scale[b], is = 1.0f / sc;
+        sc2 = sc * sc;
+        isc2 = is * is;
+      }
+      __syncthreads();  // the copy-in above is complete
+      f32x16 accC[2], accD;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accD[r] = -Dm[(di * 32 + M::row(lane, r)) * S + dj * 32 + M::col(lane)] * sc2;
+        const int ci = wave * 32 + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) accC[fn][r] = -Cw[ci * S + fn * 32 + M::col(lane)] * sc2;
+      }
+      pl.run(pst, nblk, accC, accD, di, dj);
+      STAMP(1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // every element belongs to exactly one lane
+        Dm[(di * 32 + M::row(lane, r)) * S + dj * 32 + M::col(lane)] = -accD[r] * isc2;
+        const int ci = wave * 32 + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) Cw[ci * S + fn * 32 + M::col(lane)] = -accC[fn][r] * isc2;
+      }
+    }
+  }
+  if (!PL && c0 > cJ) {
     // The accumulators START from the (negated) block and the products are added to them:
     // acc = -C + sum_k P P^T, stored back negated.  Summing the products first and subtracting the
     // sum from C afterwards loses the small terms against the large first one on nearly rank-one
@@ -437,9 +587,9 @@ __global__ __launch_bounds__(NTHREADS) void potrf_panel_kernel(VRows<T> vr, int6
     if (rp == nullptr) continue;
     T *dst = rp + c0 + j;
     if constexpr (sizeof(T) == 4) {
-      // rows below the outer block also go out as three bf16 planes [plane][row][256]: the operand of
-      // the bf16 x 3 trailing update (potrf_syrk_b3_kernel), pieces summing to the float exactly
-      if (o3.p != nullptr && (o3.whole || rbase + s >= cJ + NBO)) {
+      // the rows also go out as three bf16 planes: the operand of the bf16 x 3 trailing update
+      // (potrf_syrk_b3_kernel) and of the next launches' left-looking update, pieces summing to the float exactly
+      if (o3.p != nullptr) {  // (the rows inside the outer block too: the next launches' left-looking update reads them)
         __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (c0 - o3.col0) + j;
         if (o3.np == 2) {
           const float sc = o3.scale[b];
@@ -861,7 +1011,18 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     for (int64_t c0 = cJ; c0 < kend; c0 += NB) {
       const int64_t below = Mv - (c0 + NB);
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
-      hipLaunchKernelGGL((potrf_panel_kernel<T, VECM>), dim3((unsigned)nwg, (unsigned)batch),
+      if constexpr (sizeof(T) == 4 && VECM) {
+        if (b3) {
+          if (o3.np == 2)
+            hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 2>), dim3((unsigned)nwg, (unsigned)batch),
+                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+          else
+            hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 3>), dim3((unsigned)nwg, (unsigned)batch),
+                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+          continue;
+        }
+      }
+      hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 0>), dim3((unsigned)nwg, (unsigned)batch),
                          dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work,
                          o3, g_stamps);
     }

@@ -8,7 +8,8 @@ lib.gpvae_dev_set_stamps(C.c_void_p(st.data_ptr()))
 for dt in (torch.float32,):
     n = 4096
     g = torch.arange(n, device=dev, dtype=dt) / n
-    K = ops.gram_se(g, g, 1.0, 0.05, 1e-3)
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    K = ops.gram_se(g, g, torch.ones(batch, device=dev, dtype=dt), torch.full((batch,), 0.05, device=dev, dtype=dt), 1e-3)
     ops.potrf_(K, zero_upper=False, nan_on_fail=False)
     torch.cuda.synchronize()
     s = st.cpu().numpy().reshape(128, 8)
