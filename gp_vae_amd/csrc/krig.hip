@@ -300,7 +300,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void krig_small_kernel(int n, int64_t 
   using M16 = Mfma16<T>;
   using V = typename VecT<T>::type;
   constexpr int KV = VecT<T>::N, CK = 4 * KV, NC = KP / CK, MT16 = KP / 16;
-  const int lr = lane & 15, g = lane >> 4, half = wave & 1, mset = wave >> 1;
+  // (half, mset) from a scalar wave index: `mine` below gates MFMAs, which do not honour EXEC — a real branch
+  const int wsc = __builtin_amdgcn_readfirstlane(wave);
+  const int lr = lane & 15, g = lane >> 4, half = wsc & 1, mset = wsc >> 1;
   T wreg[MT16][4];
   bool rok[MT16][4];
 #pragma unroll

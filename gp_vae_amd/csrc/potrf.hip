@@ -688,7 +688,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
   using Pipe = PipeKC<T, F, F, SBK, SBM, SBM, LA, LA>;
   static_assert(Pipe::LD == LD, "image stride");
   __shared__ __align__(16) T lds[Pipe::LDS_ELEMS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave as a scalar: `wanted` below gates MFMAs, and an MFMA does not honour EXEC — the gate must be a real branch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   vr.A += (int64_t)b * strideA;
   if (vr.X) vr.X += (int64_t)b * strideX;
   const int64_t n = vr.n;
