@@ -569,8 +569,44 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
   // the caller's scratch (dense 64x64 per diagonal block) and potrf_finalize_kernel puts it in place.
   const int nst = (NCH + (blockIdx.x == 0 ? 1 : 0)) * NB * VPR;
   T *l11 = dwork + ((int64_t)b * (vr.npad / NB) + c0 / NB) * (NB * NB);
+  if constexpr (PL) {
+    // planes route (whole 64-column blocks of real rows): 8 columns per lane, so that every plane goes out as
+    // 16-byte stores — 5 store instructions per 8 elements instead of 8 (the phase is bound by their issue rate)
+    float sc = 1.0f;
+    if constexpr (NPL == 2) sc = o3.scale[b];
+#pragma unroll 2
+    for (int idx = tid; idx < NCH * NB * 8; idx += NTHREADS) {
+      const int s = idx >> 3, j = (idx & 7) * 8;
+      T *rp = vr.ptr(rbase + s);
+      if (rp == nullptr) continue;
+      const V t0 = *reinterpret_cast<const V *>(&Cw[s * S + j]), t1 = *reinterpret_cast<const V *>(&Cw[s * S + j + 4]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = reinterpret_cast<const float *>(&t0)[e];
+        v[4 + e] = reinterpret_cast<const float *>(&t1)[e];
+      }
+      __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s) * o3.ld + (c0 - o3.col0) + j;
+      if constexpr (NPL == 2) {
+        _Float16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2_f16(v[e] * sc, hh[e], ll[e]);
+        *reinterpret_cast<i32x4_t *>(q) = *reinterpret_cast<const i32x4_t *>(hh);
+        *reinterpret_cast<i32x4_t *>(q + o3.plane) = *reinterpret_cast<const i32x4_t *>(ll);
+      } else {
+        __bf16 hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3_bf16(v[e], hh[e], mm[e], ll[e]);
+        *reinterpret_cast<i32x4_t *>(q) = *reinterpret_cast<const i32x4_t *>(hh);
+        *reinterpret_cast<i32x4_t *>(q + o3.plane) = *reinterpret_cast<const i32x4_t *>(mm);
+        *reinterpret_cast<i32x4_t *>(q + 2 * o3.plane) = *reinterpret_cast<const i32x4_t *>(ll);
+      }
+      *reinterpret_cast<V *>(rp + c0 + j) = t0;
+      *reinterpret_cast<V *>(rp + c0 + j + 4) = t1;
+    }
+  }
 #pragma unroll 4
-  for (int idx = tid; idx < nst; idx += NTHREADS) {
+  for (int idx = PL ? NCH * NB * VPR + tid : tid; idx < nst; idx += NTHREADS) {
     const int s = idx / VPR, j = (idx % VPR) * VEC;  // s < NCH*NB: chunk rows; beyond: L11 (block 0)
     const bool is_l11 = s >= NCH * NB;
     const int li = s - NCH * NB;
