@@ -811,9 +811,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void potrf_syrk_kernel(
 // (f32 accumulators stored and reloaded between launches lose nothing: the factor is bit-identical to D = 1),
 // but a tile's C load, pipeline fill and store (~6 us) are paid per 8 D k-tiles instead of per 8.
 struct SyrkB3Map {
-  int R, batch;   // 256-row tile rows of the trailing matrix
-  int64_t per;    // R (R + 1) tiles per matrix; narrow (the first 256 columns only): 2 R
+  int R, batch;   // tile rows of the trailing matrix (256 rows each; 128 with half)
+  int64_t per;    // tiles per matrix: R (R + 1) (half: R (R + 1) / 2); narrow, the first 256 columns only: 2 R (2 R - 1)
   int narrow;
+  int half;       // 128 x 128 tiles (PipeB3T<2>): twice the workgroups for launches whose 256-row tiles fill their
+                  // last round of 256 CUs badly
+  __host__ static int64_t tiles(int R, bool narrow, bool half) {
+    if (half) return narrow ? 2 * (int64_t)R - 1 : (int64_t)R * (R + 1) / 2;
+    return narrow ? 2 * (int64_t)R : (int64_t)R * (R + 1);
+  }
   __host__ int64_t grid() const {
     return batch >= 8 ? 8 * (int64_t)((batch + 7) / 8) * per : (int64_t)batch * per;
   }
@@ -829,6 +835,19 @@ struct SyrkB3Map {
     } else {
       b = (int)(id / per);
       p = id - (int64_t)b * per;
+    }
+    if (half) {  // square tiles: tc <= tr
+      if (narrow) {  // (0,0), (1,0), (1,1), (2,0), (2,1), ...
+        tr = (int)((p + 1) >> 1);
+        tc = p == 0 ? 0 : (int)((p + 1) & 1);
+        return true;
+      }
+      int r = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+      while ((int64_t)r * (r + 1) / 2 > p) --r;
+      while ((int64_t)(r + 1) * (r + 2) / 2 <= p) ++r;
+      tr = r;
+      tc = (int)(p - (int64_t)r * (r + 1) / 2);
+      return true;
     }
     if (narrow) {
       tr = (int)(p >> 1);
@@ -846,21 +865,22 @@ struct SyrkB3Map {
 
 // NP = 2: the planes hold L * s (fp16 x 2, b3.hpp); the accumulators start from -C s^2 and are multiplied by
 // 1 / s^2 before the store (powers of two: exact).
-template <int NP>
+template <int NP, int WFM>
 __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
                                                                     int64_t strideA, B3Out o3,
                                                                     int64_t cP, int K, int64_t kend,
                                                                     SyrkB3Map map) {
   using M = Mfma<float>;
-  using PipeB3 = PipeB3T<4, NP>;
+  using PipeB3 = PipeB3T<WFM, NP>;
+  constexpr int TM = PipeB3::TM;  // 256 (WFM = 4) or 128 (WFM = 2: map.half)
   __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
   int b, tr, tc;
   if (!map.decode(blockIdx.x, b, tr, tc)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *Ab = A + (int64_t)b * strideA;
   const __bf16 *Pb = o3.p + (int64_t)b * o3.stride + (cP - o3.col0);  // row 0, first column of the K panel columns
-  const int64_t r0 = kend + (int64_t)tr * B3_TM, q0 = kend + (int64_t)tc * B3_TN;
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  const int64_t r0 = kend + (int64_t)tr * TM, q0 = kend + (int64_t)tc * B3_TN;
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 64;
   PipeB3 P;
   P.init(Pb + r0 * o3.ld, o3.ld, o3.plane, Pb + q0 * o3.ld, o3.ld, o3.plane, tid, wm, wn);
   TileIO<float> io;
@@ -899,7 +919,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] *= is2;
   }
-  if (tc < 2 * tr) {  // wholly below the diagonal
+  if (WFM == 4 ? tc < 2 * tr : tc < tr) {  // wholly below the diagonal
 #pragma unroll
     for (int fm = 0; fm < PipeB3::WFM; ++fm)
 #pragma unroll
@@ -1069,14 +1089,22 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
         // inside a group: the next 256 columns only, with every column of the group so far (with one block
         // left that is the whole update); after its last block: everything right of the group
         const bool narrow = jj + 1 < D && R > 1;
-        const SyrkB3Map map{R, batch, narrow ? 2 * (int64_t)R : (int64_t)R * (R + 1), narrow ? 1 : 0};
+        // 256 x 128 or 128 x 128 tiles: whichever needs less time in rounds of 256 workgroups (one per CU); a
+        // 128-row tile takes 0.53 of a 256-row one (half the MFMAs per k-tile against two thirds of the operand bytes)
+        SyrkB3Map map{R, batch, SyrkB3Map::tiles(R, narrow, false), narrow ? 1 : 0, 0};
+        const SyrkB3Map hmap{2 * R, batch, SyrkB3Map::tiles(2 * R, narrow, true), narrow ? 1 : 0, 1};
+        if (0.53 * (double)cdiv(hmap.grid(), (int64_t)256) < (double)cdiv(map.grid(), (int64_t)256)) map = hmap;
         const int K = (jj + 1) * NBO;
-        if (o3.np == 2)
-          hipLaunchKernelGGL(potrf_syrk_b3_kernel<2>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                             lda, strideA, o3, cP, K, kend, map);
-        else
-          hipLaunchKernelGGL(potrf_syrk_b3_kernel<3>, dim3((unsigned)map.grid()), dim3(NTHREADS), 0, st, (float *)A,
-                             lda, strideA, o3, cP, K, kend, map);
+        const dim3 grid((unsigned)map.grid());
+#define GPVAE_SYRK_B3(NPV, WFMV)                                                                              \
+  hipLaunchKernelGGL((potrf_syrk_b3_kernel<NPV, WFMV>), grid, dim3(NTHREADS), 0, st, (float *)A, lda, strideA, o3, cP, \
+                     K, kend, map)
+        if (o3.np == 2) {
+          if (map.half) GPVAE_SYRK_B3(2, 2); else GPVAE_SYRK_B3(2, 4);
+        } else {
+          if (map.half) GPVAE_SYRK_B3(3, 2); else GPVAE_SYRK_B3(3, 4);
+        }
+#undef GPVAE_SYRK_B3
         continue;
       }
     }
