@@ -26,13 +26,13 @@ namespace gpvae {
 constexpr int NB = 64;     // inner (panel) block
 constexpr int NBO = 256;   // outer block
 // outer blocks per group of the delayed trailing update (bf16 x 3 path; potrf_syrk_b3_kernel).  Measured at batch
-// 16, f32 (ms, groups of 1 / 2 / 4): n = 1024: 0.560 / 0.570 / 0.592, 2048: 1.311 / 1.296 / 1.346,
-// 4096: 4.86 / 4.43 / 4.37 (batch 32: 8.62 / 7.64 / 7.50) — the narrow launches of a group fill the chip only
-// when the matrix is tall
+// 16, f32 (ms, groups of 1 / 2 / 4 / 8, with the 128 x 128 tiles for badly filled launches): n = 1024: 0.473 / 0.455 /
+// 0.469 / 0.476, 2048: 1.153 / 1.112 / 1.146 / 1.172, 4096: 4.44 / 4.04 / 3.90 / 3.95 (batch 32: 8.00 / 7.11 /
+// 6.82 / 6.85) — the narrow launches of a group fill the chip only when the matrix is tall
 // the same on the f32 / f64 MFMA trailing update (potrf_syrk_kernel; groups of 1 / 2 / 4): f64 16 x 4096 10.25 / 9.68 /
 // 9.88 ms, f64 16 x 2048 2.24 / 2.22 / 2.40, f32 16 x 4000 5.61 / 5.30 / 5.39, f64 2 x 8192 12.1 / 11.9 / 12.4
 static inline int mfma_group(int64_t n) { return n >= 15 * NBO ? 2 : 1; }
-static inline int b3_group(int64_t n) { return n >= 16 * NBO ? 4 : (n >= 8 * NBO ? 2 : 1); }
+static inline int b3_group(int64_t n) { return n >= 16 * NBO ? 4 : (n >= 4 * NBO ? 2 : 1); }
 
 // developer probe (make DEV=1 builds only): when set (gpvae_dev_set_stamps), block (0,0) of the panel
 // launch of column block c0/64 writes s_memtime at its phase boundaries to stamps[8*(c0/64) + 0..7].

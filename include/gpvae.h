@@ -81,7 +81,7 @@ int gpvae_gram_agg(void *stream, int dtype, int d, int64_t n_cells, int m, const
  * parked there until the last launch (late workgroups of a panel launch never see a half-updated A),
  * and — float32 with n % 256 == 0, n >= 512 and m_extra == 0 — behind them batch * 3 * n * 256 g bf16
  * values: the current group of g 256-column panels as three bf16 planes (exact 8+8+8-bit split of every
- * float; g = 1 below n = 2048, 2 below 4096, else 4).  On that route the trailing updates C -= P P^T run on
+ * float; g = 1 below n = 1024, 2 below 4096, else 4).  On that route the trailing updates C -= P P^T run on
  * the bf16 matrix pipe from those planes (six piece products per float product, f32 accumulation:
  * float32-accurate, csrc/b3.hpp), delayed so that all columns right of a group are updated once per group
  * with K = 256 g (same sums in the same order: bit-identical to g = 1); every other shape and dtype uses

@@ -137,10 +137,11 @@ def test_size_queries():
     assert lib.gpvae_vae_workspace_bytes(1, 100, n, h0, h1, z) >= 100 * n * 8
     assert lib.gpvae_krig_workspace_bytes(1, 100, 50) >= (100 * 100 + 51 * 100) * 8
     # f32, n % 256 == 0, no extra rows: parked diagonal blocks + the current group of outer panels (4 at
-    # n >= 4096, 2 at n >= 2048, else 1) as three bf16 planes
+    # n >= 4096, 2 at n >= 1024, else 1) as three bf16 planes
     assert lib.gpvae_potrf_workspace_bytes(0, 4096, 0, 32) == 32 * 4096 * 64 * 4 + 32 * 3 * 4096 * 1024 * 2
     assert lib.gpvae_potrf_workspace_bytes(0, 2048, 0, 2) == 2 * 2048 * 64 * 4 + 2 * 3 * 2048 * 512 * 2
-    assert lib.gpvae_potrf_workspace_bytes(0, 1024, 0, 2) == 2 * 1024 * 64 * 4 + 2 * 3 * 1024 * 256 * 2
+    assert lib.gpvae_potrf_workspace_bytes(0, 1024, 0, 2) == 2 * 1024 * 64 * 4 + 2 * 3 * 1024 * 512 * 2
+    assert lib.gpvae_potrf_workspace_bytes(0, 768, 0, 2) == 2 * 768 * 64 * 4 + 2 * 3 * 768 * 256 * 2
     assert lib.gpvae_potrf_workspace_bytes(0, 4096, 5, 32) == 32 * 4096 * 64 * 4
     assert lib.gpvae_potrf_workspace_bytes(1, 4096, 0, 32) == 32 * 4096 * 64 * 8
     assert lib.gpvae_potrf_workspace_bytes(1, 100, 7, 2) == 2 * 128 * 64 * 8
