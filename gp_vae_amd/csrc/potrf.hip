@@ -79,12 +79,19 @@ struct B3Out {
 template <typename T> struct PanelCfg;
 template <> struct PanelCfg<float> {
   static constexpr int BK = 32;  // k-tile of the staged update GEMM
+  static constexpr int BK3 = 32; // (three-chunk form: float64 only)
   static constexpr int NCH = 2;  // 64-row chunks per workgroup (one per wave in the solve)
   static constexpr int S = 68;   // LDS row stride of the 64-wide blocks (16-B aligned rows,
                                  // ds_read_b128 of one row per lane is conflict free: 17 slots/row)
 };
 template <> struct PanelCfg<double> {
   static constexpr int BK = 16;
+  // Three chunks per workgroup (NCHV = 3 below): the float64 images of two chunks take 129 KB of LDS, one workgroup
+  // per CU, so at batch 16 x 4096 the launches of the first eight outer blocks need two rounds of workgroups
+  // (54 + 75 + 91 + 107 us per outer block against 26 + 35 + 43 + 51 in one round).  With k-tiles of 8 instead of
+  // 16 in the staged update a third chunk fits (156 KB), and a launch that then needs fewer rounds takes that form
+  // (the products are added in the same k order: the factor is the same bits).
+  static constexpr int BK3 = 8;
   static constexpr int NCH = 2;
   static constexpr int S = 66;
 };
@@ -347,7 +354,7 @@ template <int NP> struct PanelB3 {
 
 // NPL = 3 / 2: the rows exist as bf16 / fp16 planes (B3Out) and the left-looking update runs on them (float32
 // only); NPL = 0: the update on the f32 / f64 MFMA from A itself
-template <typename T, bool VECM, int NPL>
+template <typename T, bool VECM, int NPL, int NCHV = 0>
 __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRows<T> vr, int64_t strideA,
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, T *dwork,
@@ -355,7 +362,8 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
                                                                unsigned long long *stamps) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
-  constexpr int NCH = Cfg::NCH, S = Cfg::S, PBK = Cfg::BK;
+  constexpr int NCH = NCHV ? NCHV : Cfg::NCH, S = Cfg::S, PBK = NCHV == 3 ? Cfg::BK3 : Cfg::BK;
+  static_assert(NCHV == 0 || (NCHV == 3 && sizeof(T) == 8 && NPL == 0), "three chunks: the float64 form");
   constexpr int SROWS = NB + NB * NCH;              // stacked rows: diagonal block + chunks
   constexpr int LDT = PBK + RmPad<T>::V;            // row-major staging image [SROWS][LDT]
   constexpr int RPW = 16 * NCH;                     // chunk rows per wave in the GEMM phase
@@ -1029,6 +1037,17 @@ __global__ __launch_bounds__(256) void potrf_h2_scale_kernel(const float *A, int
   }
 }
 
+// compute units of the current device (rounds of one-per-CU workgroups are counted against it)
+static inline int64_t cu_count() {
+  static int cached[64] = {0};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] > 0) return cached[dev];
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+  cached[dev] = v;
+  return v;
+}
+
 // workspace: [parked diagonal blocks | bf16 planes of the current outer panel (b3 path only)]
 static inline int64_t l11_bytes(int64_t es, int64_t n, int batch) {
   return round_up((int64_t)batch * round_up(n, NB) * NB * es, 256);
@@ -1060,6 +1079,7 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     return -12;
   }
   const int D = b3 ? b3_group(n) : mfma_group(n);
+  const int64_t ncu = cu_count();
   for (int64_t cJ = 0; cJ < n; cJ += NBO) {
     const int64_t kend = (cJ + NBO < n) ? cJ + NBO : n;
     const int jj = (int)((cJ / NBO) % D);          // position in the group of D outer blocks (b3 path)
@@ -1076,6 +1096,15 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
           else
             hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 3>), dim3((unsigned)nwg, (unsigned)batch),
                                dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+          continue;
+        }
+      }
+      if constexpr (sizeof(T) == 8) {
+        // three chunks per workgroup where that saves a round of workgroups (one per CU): PanelCfg<double>
+        const int64_t nwg3 = below > 0 ? cdiv(below, (int64_t)NB * 3) : 1;
+        if (cdiv(nwg3 * batch, ncu) < cdiv(nwg * batch, ncu)) {
+          hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 0, 3>), dim3((unsigned)nwg3, (unsigned)batch),
+                             dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
           continue;
         }
       }

@@ -234,6 +234,32 @@ def test_potrf_delayed_trailing_update_ragged_with_extra_rows(ops, ndt, tdt, tol
             assert rel(Lg, L64) < t and rel(Xd[b], want) < ts
 
 
+def test_potrf_f64_three_chunk_panel_launches(ops):
+    """float64 panel launches take three 64-row chunks per workgroup where that saves a round of one-per-CU
+    workgroups (potrf.hip PanelCfg<double>): batch 48 x n = 1024 (+ 70 extra rows) has such launches, the same
+    matrices factored one at a time have none — same bits either way, and the factor against the oracle."""
+    rng = np.random.default_rng(5)
+    n, m, batch = 1024, 70, 48
+    x = rng.random((n, 2))
+    ls = np.linspace(0.05, 0.6, batch)
+    K = np.stack([orc.exp_kernel2(x, x, 1.0, l, 1e-3) for l in ls])
+    K[7, 600, 600] = -1.0  # not positive definite from column 600 on: info must say so in the batched call too
+    X = rng.standard_normal((batch, m, n))
+    A, Xd = dev(K, torch.float64), dev(X, torch.float64)
+    info = ops.potrf_(A, Xd, zero_upper=True, nan_on_fail=False)
+    want = [0] * batch
+    want[7] = 601
+    assert info.cpu().tolist() == want
+    for b in (0, 7, 20, 47):
+        A1, X1 = dev(K[b:b + 1], torch.float64), dev(X[b:b + 1], torch.float64)
+        i1 = ops.potrf_(A1, X1, zero_upper=True, nan_on_fail=False)
+        assert i1.item() == want[b]
+        assert torch.equal(torch.nan_to_num(A1[0]), torch.nan_to_num(A[b]))
+        assert torch.equal(torch.nan_to_num(X1[0]), torch.nan_to_num(Xd[b]))
+    L64 = np.linalg.cholesky(K[20])
+    assert rel(A[20], L64) < 1e-10 and rel(Xd[20], orc.right_solve_lt(L64, X[20])) < 1e-9
+
+
 def test_potrf_overlapped_sub_batches(ops):
     """The sub-batch / side-stream form gives the factors and info values of the plain call."""
     rng = np.random.default_rng(31)
