@@ -46,6 +46,12 @@ N = GRID * GRID
 B = 4096
 DIMS = (50, 30, 15)  # 2d_examples.py hidden_dims / z_dim
 JITTER = 1.0e-3      # 2d_examples.py:503
+# HIP events bracket every 3rd launch of the draw in the timed region (roofline.avg_launch_ms): an event record
+# costs the stream ~5.6 us (kernel trace), so timing every launch took up to 11 us out of every step (measured:
+# 0.775-0.778 ms per step with every launch timed, 0.770 with every 3rd).  3 is coprime to the factor group of 16:
+# every 4th launch would sample the group's first step — the one beside the factor stream's Gram build — four
+# times as often as it occurs (0.505 against 0.444 ms in-loop).
+DRAW_EVENTS_EVERY = int(os.environ.get("GPVAE_DRAW_EVENTS_EVERY", "3"))
 LR = 1.0e-3
 
 
@@ -409,6 +415,7 @@ def main():
 
     eng.run([(0, i) for i in range(args.warmup)], state, train=True)
     eng.draw_events = []
+    eng.draw_events_every = DRAW_EVENTS_EVERY  # the draw's launches are timed live, every 3rd of them
     barrier()
     t0 = time.perf_counter()
     eng.run([(1, i) for i in range(args.steps)], state, train=True)
@@ -423,7 +430,9 @@ def main():
         elapsed = float(tt[0].item())
     rccl_world = dist.get_world_size() if dist.is_initialized() else 1
     draw_ms = float(np.mean([a.elapsed_time(b) for a, b in eng.draw_events])) if eng.draw_events else None
+    draw_timed = len(eng.draw_events) if eng.draw_events else 0
     eng.draw_events = None
+    eng.draw_events_every = 1
     loss_last = float(eng.loss.item())
     draw_alone_ms = eng.time_draw_alone() if rank == 0 else None
 
@@ -462,6 +471,8 @@ def main():
                     "f32_equivalent_frac_of_f32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS if f32_equiv else None}
             roof["mfma_only_sustained_tflops_random_operands"] = SUSTAINED_BF16_MFMA_RANDOM_TFLOPS
             roof["frac_of_mfma_only_sustained"] = 6 * f32_equiv / SUSTAINED_BF16_MFMA_RANDOM_TFLOPS if f32_equiv else None
+            roof["launches_timed"] = "%d of %d (every launch number divisible by %d in the timed region, HIP events on its stream)" % (
+                draw_timed, args.steps, DRAW_EVENTS_EVERY)
             if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
                 roof["avg_launch_ms_alone"] = draw_alone_ms
                 roof["frac_alone"] = 6 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS

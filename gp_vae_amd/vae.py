@@ -275,7 +275,7 @@ class StepEngine():
 
     def __init__(self, x, jitter, dims, batch_size, lr, dtype=torch.float32, seed=0, obs_sigma=0.1,
                  hyper_sampler=draw_hyper, overlap=True, group=None, kernel=exp_kernel2, mfma="auto",
-                 first_group=None):
+                 first_group=None, group_normals=True):
         self.first_group = first_group  # int or sequence: sizes of the first factor groups; None: default_ramp
         self.default_ramp = ()
         if isinstance(hyper_sampler, str) and hyper_sampler != "device":
@@ -356,12 +356,37 @@ class StepEngine():
         self.work = ops.VaeWorkspace(B, n, self.h0, self.h1, self.z, dtype, dev)
         self.overlap = overlap
         self.s_gp, self.s_rng = _side_streams(dev) if overlap else (None, None)
+        # Normals of a whole GROUP of steps at a time (round 3).  Generated per step on the side stream, the normals
+        # cost the main stream two cross-stream event operations per step (a record after the draw, a wait before the
+        # next one), and the kernel trace shows an 11-12 us hole in the main stream at each of them: 23 us of a 0.6 ms
+        # step.  They depend on nothing but (seed, rank, key), so the side stream now writes the normals of all the
+        # steps of a group into per-slot buffers as soon as the slot is free — ONE wait per group on the main stream,
+        # beside the one for the factors.  Costs G x (E planes + E' + eps_z) per slot (C3: 2 x 2.5 GiB of 288);
+        # engines whose buffers would exceed 16 GiB keep the per-step scheme.  Same Philox streams, same values.
+        es_ = self.x.element_size()
+        per_step = B * n * ((6 if self.b3 else 4 if self.h2 else es_) + es_) + B * self.z * es_
+        self.gn = bool(overlap and group_normals and 2 * G * per_step <= (16 << 30)
+                       and os.environ.get("GPVAE_GROUP_NORMALS", "1") != "0")  # the variable: A/B measurements
+        if self.gn:
+            if self.b3:
+                self.E3g = [torch.empty((G, 3, B, n), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+            elif self.h2:
+                self.Ehg = [torch.empty((G, 2, B, n), dtype=torch.float16, device=dev) for _ in range(2)]
+            else:
+                self.Eg = [torch.empty((G, B, n), dtype=dtype, device=dev) for _ in range(2)]
+            self.E2g = [torch.empty((G, B, n), dtype=dtype, device=dev) for _ in range(2)]
+            self.ezg = [torch.empty((G, B, self.z), dtype=dtype, device=dev) for _ in range(2)]
+            self.ev_rng_ready = [torch.cuda.Event() for _ in range(2)]
         self.ev_drawn, self.ev_rng = torch.cuda.Event(), torch.cuda.Event()
         self._rng_pending = False
         self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # factors of group slot s are ready
         self.ev_free = [torch.cuda.Event() for _ in range(2)]    # group slot s has been consumed
         self.ev_copied = [torch.cuda.Event() for _ in range(2)]  # slot s's hyper upload is done
         self.draw_events = None  # bench.py: list of (start, end) HIP events around gpvae_draw
+        # ... around every draw_events_every-th draw: an event record costs the stream ~5.6 us (kernel trace: a hole
+        # of that size on either side of every bracketed draw, 11 us of a 0.55 ms step when every launch is timed)
+        self.draw_events_every = 1
+        self._draw_calls = 0
         # The small configurations (C1, C2) are bound by the host's launch rate, so the per-step path below
         # makes no tensor views and no wrapper calls: raw device pointers are taken once here, the library is
         # called with explicit stream handles (no stream context switches), six ABI calls per step
@@ -381,6 +406,15 @@ class StepEngine():
         else:
             self._pE = vp(self.E.data_ptr())
         self._pE2 = vp(self.E2.data_ptr())
+        if self.gn:
+            Eg = self.E3g if self.b3 else (self.Ehg if self.h2 else self.Eg)
+            Ebytes = B * n * (6 if self.b3 else 4 if self.h2 else es)
+            self._pEg = [[vp(Eg[s].data_ptr() + i * Ebytes) for i in range(G)] for s in range(2)]
+            self._pE2g = [[vp(self.E2g[s].data_ptr() + i * B * n * es) for i in range(G)] for s in range(2)]
+            self._pezg = [[vp(self.ezg[s].data_ptr() + i * B * self.z * es) for i in range(G)] for s in range(2)]
+        self._cur_ez = [None, None]  # eps_z of the step in draw buffer 0 / 1
+        self._gn_run = False         # run() sets it: this run takes its normals from the group buffers
+        self.gn_at = 8               # ... issued this many sixteenths of a group after the group before it starts
         self._pY = [vp(t.data_ptr()) for t in self.Ybuf]
         self._pez = [vp(t.data_ptr()) for t in self.ezbuf]
         self._pgrads = vp(self.grads.data_ptr())
@@ -443,21 +477,31 @@ class StepEngine():
             self.ev_ready[slot].record(stream)
 
     # -- stage B: draws + ELBO (+ update) on the current stream ----------------------------------------
-    def _normals(self, key, buf, h):
+    def _normals(self, key, buf, h, dst=None):
         """The step's standard normals (Philox streams keyed by rank, key, purpose — parallel.philox_stream_id):
-        E (as bf16 planes on the bf16 x 3 path), E', eps_z into draw buffer `buf`, on the stream with handle h."""
+        E (as bf16 planes on the bf16 x 3 path), E', eps_z into draw buffer `buf` — or into dst = (E, E', eps_z)
+        pointers of a group slot —, on the stream with handle h."""
         lib, n, B, seed = self._lib, self.n, self.B, self.seed
         sid = ((self.rank & 0xFF) << 56) | ((int(key[0]) & 0xFFFFFF) << 28) | ((int(key[-1]) & 0xFFFFFF) << 4)
+        pE, pE2, pez = dst if dst is not None else (
+            self._pE3 if self.b3 else (self._pEh if self.h2 else self._pE), self._pE2, self._pez[buf])
         if self.b3:
-            rc = lib.gpvae_randn_b3(h, B * n, seed, sid | 1, self._pE3, B * n)
+            rc = lib.gpvae_randn_b3(h, B * n, seed, sid | 1, pE, B * n)
         elif self.h2:
-            rc = lib.gpvae_randn_h2(h, B * n, seed, sid | 1, self._pEh, B * n)
+            rc = lib.gpvae_randn_h2(h, B * n, seed, sid | 1, pE, B * n)
         else:
-            rc = lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 1, self._pE)
-        rc = rc or lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 2, self._pE2)
-        rc = rc or lib.gpvae_randn(h, self._dtc, B * self.z, seed, sid | 3, self._pez[buf])
+            rc = lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 1, pE)
+        rc = rc or lib.gpvae_randn(h, self._dtc, B * n, seed, sid | 2, pE2)
+        rc = rc or lib.gpvae_randn(h, self._dtc, B * self.z, seed, sid | 3, pez)
         if rc:
             check(rc, "gpvae_randn")
+
+    def _issue_normals(self, keys, slot):
+        """Group mode: the normals of every step of the group into slot `slot`, on the normals stream."""
+        self.s_rng.wait_event(self.ev_free[slot])  # the steps that read this slot's buffers are done
+        for i, key in enumerate(keys):
+            self._normals(key, 0, self._h_rng, (self._pEg[slot][i], self._pE2g[slot][i], self._pezg[slot][i]))
+        self.ev_rng_ready[slot].record(self.s_rng)
 
     def _produce(self, key, slot, i, last_of_group, buf, next_key=None):
         """The B draws of one step into draw buffer `buf` (main stream).  The normals of the NEXT step are
@@ -467,29 +511,43 @@ class StepEngine():
         main, hm = self._main, self._h_main
         if self.overlap and i == 0:
             main.wait_event(self.ev_ready[slot])
-        if self._rng_pending:
-            main.wait_event(self.ev_rng)      # this step's normals came from the side stream
-            self._rng_pending = False
+        gn = self.gn and self._gn_run
+        if gn:
+            if self.overlap and i == 0:
+                main.wait_event(self.ev_rng_ready[slot])  # the whole group's normals
+            pE, pE2 = self._pEg[slot][i], self._pE2g[slot][i]
+            self._cur_ez[buf] = self._pezg[slot][i]
         else:
-            self._normals(key, buf, hm)
+            pE, pE2 = (self._pE3 if self.b3 else (self._pEh if self.h2 else self._pE)), self._pE2
+            self._cur_ez[buf] = self._pez[buf]
+            if self._rng_pending:
+                main.wait_event(self.ev_rng)      # this step's normals came from the side stream
+                self._rng_pending = False
+            else:
+                self._normals(key, buf, hm)
         lib, n = self._lib, self.n
+        ev = None
         if self.draw_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record(main)
+            if self._draw_calls % self.draw_events_every == 0:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(main)
+            self._draw_calls += 1
         if self.b3:
-            rc = lib.gpvae_draw_b3(hm, n, self.B, self._pL3[slot][i], n, n * n, self._pE3, n, self.B * n,
-                                   self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
+            rc = lib.gpvae_draw_b3(hm, n, self.B, self._pL3[slot][i], n, n * n, pE, n, self.B * n,
+                                   pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
         elif self.h2:
-            rc = lib.gpvae_draw_h2(hm, n, self.B, self._pL2[slot][i], n, n * n, self._pL2inv[slot][i], self._pEh, n,
-                                   self.B * n, self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
+            rc = lib.gpvae_draw_h2(hm, n, self.B, self._pL2[slot][i], n, n * n, self._pL2inv[slot][i], pE, n,
+                                   self.B * n, pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
         else:
-            rc = lib.gpvae_draw(hm, self._dtc, n, self.B, self._pK[slot][i], self.ld, self._pE, n,
-                                self._pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
+            rc = lib.gpvae_draw(hm, self._dtc, n, self.B, self._pK[slot][i], self.ld, pE, n,
+                                pE2, n, self._psig[slot][i], None, 0, self._pY[buf], n)
         if rc:
             check(rc, "gpvae_draw")
-        if self.draw_events is not None:
+        if ev is not None:
             ev[1].record(main)
             self.draw_events.append(ev)
+        if gn:
+            return  # the slot is released after the group's last ELBO (run): it also reads the slot's eps_z
         if self.overlap and next_key is not None:
             self.ev_drawn.record(main)
             self.s_rng.wait_event(self.ev_drawn)
@@ -503,7 +561,7 @@ class StepEngine():
         """ELBO (+ gradient) of the step in draw buffer `buf`; starts the one collective of the path
         (flat-gradient SUM, RCCL over xGMI) and returns its handle."""
         rc = self._lib.gpvae_vae_elbo(self._h_main, self._dtc, self.B, self.n, self.h0, self.h1, self.z, self._pparams,
-                                      self._pY[buf], self.n, self._pez[buf], float(self.obs_sigma),
+                                      self._pY[buf], self.n, self._cur_ez[buf], float(self.obs_sigma),
                                       C.c_void_p(self._loss_base + t * self._loss_es),
                                       self._pgrads if train else None, self._pwork)
         if rc:
@@ -529,6 +587,7 @@ class StepEngine():
         self._main, self._h_main = main, C.c_void_p(main.cuda_stream)
         keep, self.draw_events = self.draw_events, []
         was, self.overlap = self.overlap, False
+        was_gn = self._gn_run  # (a run in group mode left real normals in slot 0's buffers: the draw reads those)
         try:
             for r in range(reps + 2):
                 self._rng_pending = True  # keep the normals already in the buffers: time the draw only
@@ -536,7 +595,7 @@ class StepEngine():
             torch.cuda.synchronize()
             ms = [a.elapsed_time(b) for a, b in self.draw_events[2:]]
         finally:
-            self.overlap, self.draw_events, self._rng_pending = was, keep, False
+            self.overlap, self.draw_events, self._rng_pending, self._gn_run = was, keep, False, was_gn
         return sum(ms) / len(ms)
 
     def failed_factors(self):
@@ -588,7 +647,11 @@ class StepEngine():
         if self.overlap:
             for s in range(2):
                 self.ev_free[s].record(torch.cuda.current_stream())
+        self._gn_run = self.gn and self.overlap
+        self._rng_pending = False
         self._issue_factors(groups[0], 0)
+        if self._gn_run:
+            self._issue_normals(groups[0], 0)
         # software pipeline over steps: draw(t+1) does not depend on the parameters, so it is
         # enqueued between the start of step t's gradient all-reduce and the Adam step that waits
         # for it — the collective's latency hides behind the draw.  Same arithmetic in any order.
@@ -599,11 +662,18 @@ class StepEngine():
             if gi + 1 < len(groups):
                 self._issue_factors(groups[gi + 1], (gi + 1) & 1)
             for i, key in enumerate(grp):
+                # the next group's normals go out half a group after its factors, so that the two bursts of
+                # side-stream work do not fall on the same steps (measured: no difference to the step, 0.768-0.774 ms
+                # for 0 / 4 / 8 / 12 sixteenths; kept for the shorter queue on the normals stream)
+                if self._gn_run and gi + 1 < len(groups) and i == self.gn_at * len(grp) // 16:
+                    self._issue_normals(groups[gi + 1], (gi + 1) & 1)
                 nxt = grp[i + 1] if i + 1 < len(grp) else (groups[gi + 1][0] if gi + 1 < len(groups) else None)
                 self._produce(key, slot, i, i == len(grp) - 1, t & 1, nxt)
                 if pending is not None:
                     self._learn_finish(pending[0], state, train)
                 pending = (self._learn_start(t & 1, state, train, t),)
+                if self._gn_run and i == len(grp) - 1:
+                    self.ev_free[slot].record(self._main)  # factors, normals and eps_z of the slot have been read
                 t += 1
         if pending is not None:
             self._learn_finish(pending[0], state, train)

@@ -110,6 +110,31 @@ def test_training_run_is_bitwise_reproducible():
         assert torch.isfinite(outs[0][1]).all()
 
 
+def test_step_engine_group_normals_equal_per_step_normals():
+    """The normals of a whole group of steps written into the slot's buffers ahead of time (StepEngine's default:
+    one wait per group on the main stream) are the Philox streams the per-step scheme draws: a run ends in the same
+    bits either way, on every matrix-pipe route, across slot swaps, a short last group and a second run of the engine
+    (evaluation after training reuses the slots)."""
+    from gp_vae_amd.vae import StepEngine, SVIState
+    g = np.arange(16) / 16
+    x2 = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)  # n = 256
+    for x, B, dims, mode in [(np.tile(x2, (2, 1)) + np.repeat([[0.0, 0.0], [0.01, 0.02]], 256, 0), 256, (20, 12, 5), "bf16x3"),
+                             (np.tile(x2, (2, 1)) + np.repeat([[0.0, 0.0], [0.01, 0.02]], 256, 0), 256, (20, 12, 5), "f16x2"),
+                             (np.arange(300) / 300, 100, (35, 30, 10), "auto")]:
+        outs = []
+        for gn in (True, False):
+            eng = StepEngine(torch.tensor(x), 1e-3, dims, B, 1e-3, dtype=torch.float32, seed=3, group=4, mfma=mode,
+                             group_normals=gn)
+            assert eng.gn == gn
+            p0 = orc.flatten({k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), x.shape[0], *dims, np.float64).items()})
+            st = SVIState(torch.tensor(p0, dtype=torch.float32, device=DEV))
+            loss = eng.run([(0, i) for i in range(11)], st, train=True)
+            ev = eng.run([(1, i) for i in range(5)], st, train=False)
+            outs.append((loss.clone(), ev.clone(), st.params.clone(), st.m.clone(), st.v.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(*outs)), mode
+        assert torch.isfinite(outs[0][2]).all()
+
+
 def test_vae_fit_reference_surface_trains():
     from gp_vae_amd.gp import GP, Predictive, exp_kernel2
     from gp_vae_amd.vae import VAE
