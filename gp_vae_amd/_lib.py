@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgpvae_hip.so")
 
 F32, F64 = 0, 1
 ABI_VERSION = 2  # include/gpvae.h GPVAE_ABI_VERSION
-POTRF_ZERO_UPPER, POTRF_NAN_ON_FAIL = 1, 2
+POTRF_ZERO_UPPER, POTRF_NAN_ON_FAIL, POTRF_SHARE_CHIP = 1, 2, 4
 
 
 class GpvaeError(RuntimeError):

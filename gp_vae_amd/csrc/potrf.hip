@@ -313,7 +313,7 @@ template <int NP> struct PanelB3 {
   // accC[fn] += Pc Pd(32 fn ..)^T ; accD += Pd(32 di ..) Pd(32 dj ..)^T, smallest piece products first.
   // di, dj MUST be scalar values (readfirstlane): an MFMA does not honour EXEC, so a quadrant choice the compiler
   // takes for divergent runs all four products into accD.
-  template <int STEP>
+  template <int STEP, bool WD = true>
   __device__ __forceinline__ void mma(f32x16 (&accC)[2], f32x16 &accD, int di, int dj) {
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};  // NP == 3
     constexpr int QA[3] = {0, 1, 0}, QB[3] = {1, 0, 0};                    // NP == 2
@@ -324,6 +324,7 @@ template <int NP> struct PanelB3 {
       constexpr int F = STEP & 1;
       accC[0] = mfma(ringA[STEP][a], fb[F][bq][0], accC[0]);
       accC[1] = mfma(ringA[STEP][a], fb[F][bq][1], accC[1]);
+      if constexpr (!WD) continue;  // potrf_rows_kernel: the diagonal block was factored by an earlier launch
       if (di == 0 && dj == 0) accD = mfma(fb[F][a][0], fb[F][bq][0], accD);
       else if (di == 0) accD = mfma(fb[F][a][0], fb[F][bq][1], accD);
       else if (dj == 0) accD = mfma(fb[F][a][1], fb[F][bq][0], accD);
@@ -336,6 +337,7 @@ template <int NP> struct PanelB3 {
     load_a<0>(0); load_a<1>(0); load_a<2>(0); load_a<3>(0);
   }
   // nblk blocks of four k16 steps (64 columns each); two barriers per block
+  template <bool WD = true>
   __device__ __forceinline__ void run(unsigned char *lds, int nblk, f32x16 (&accC)[2], f32x16 &accD, int di, int dj) {
     for (int blk = 0; blk < nblk; ++blk) {
       const bool more = blk + 1 < nblk;
@@ -343,10 +345,10 @@ template <int NP> struct PanelB3 {
       __syncthreads();
       if (more) stage_load(blk + 1);
       read_b<0>(lds);
-      read_b<1>(lds); mma<0>(accC, accD, di, dj); if (more) load_a<0>(blk + 1);
-      read_b<2>(lds); mma<1>(accC, accD, di, dj); if (more) load_a<1>(blk + 1);
-      read_b<3>(lds); mma<2>(accC, accD, di, dj); if (more) load_a<2>(blk + 1);
-      mma<3>(accC, accD, di, dj); if (more) load_a<3>(blk + 1);
+      read_b<1>(lds); mma<0, WD>(accC, accD, di, dj); if (more) load_a<0>(blk + 1);
+      read_b<2>(lds); mma<1, WD>(accC, accD, di, dj); if (more) load_a<1>(blk + 1);
+      read_b<3>(lds); mma<2, WD>(accC, accD, di, dj); if (more) load_a<2>(blk + 1);
+      mma<3, WD>(accC, accD, di, dj); if (more) load_a<3>(blk + 1);
       __syncthreads();  // every wave has read this block's image
     }
   }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
                                                                int64_t strideX, int64_t c0,
                                                                int64_t cJ, int32_t *info, T *dwork,
                                                                B3Out o3,
-                                                               unsigned long long *stamps) {
+                                                               unsigned long long *stamps, int64_t rlim) {
   using M = Mfma<T>;
   using Cfg = PanelCfg<T>;
   constexpr int NCH = NCHV ? NCHV : Cfg::NCH, S = Cfg::S, PBK = NCHV == 3 ? Cfg::BK3 : Cfg::BK;
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
   if (vr.X) vr.X += (int64_t)b * strideX;
   const int64_t n = vr.n;
   const int64_t rbase = c0 + NB + (int64_t)blockIdx.x * NB * NCH;  // first chunk row (virtual)
-  const int64_t Mv = vr.npad + vr.mx;
+  // rlim: virtual rows from rlim on are left to another launch (potrf_rows_kernel): they read as absent here
+  const int64_t Mv = (vr.npad + vr.mx < rlim) ? vr.npad + vr.mx : rlim;
+  auto rowp = [&](int64_t vrow) -> T * { return vrow < rlim ? vr.ptr(vrow) : nullptr; };
 
   STAMP(0);
   int zoff;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
       const int v = tid + p * NTHREADS;
       const int s = v / VPR, j = (v % VPR) * VEC;
       const int64_t vrow = (s < NB) ? c0 + s : rbase + (s - NB);
-      const T *rp = vr.ptr(vrow);
+      const T *rp = rowp(vrow);
       const bool rok = rp != nullptr;
       const T *src = (rok ? rp : vr.A) + c0 + j;
       if (vcols) {
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
         [&](int s, int64_t &rg) -> const T * {
           const int64_t vrow = (s < NB) ? c0 + s : rbase + (s - NB);
           rg = vrow;
-          return vr.ptr(vrow);
+          return rowp(vrow);
         },
         vr.A, tid);
     kloop_kc<PBK>(
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
 #pragma unroll 2
     for (int idx = tid; idx < NCH * NB * 8; idx += NTHREADS) {
       const int s = idx >> 3, j = (idx & 7) * 8;
-      T *rp = vr.ptr(rbase + s);
+      T *rp = rowp(rbase + s);
       if (rp == nullptr) continue;
       const V t0 = *reinterpret_cast<const V *>(&Cw[s * S + j]), t1 = *reinterpret_cast<const V *>(&Cw[s * S + j + 4]);
       float v[8];
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
       *reinterpret_cast<V *>(&l11[li * NB + j]) = t;
       continue;
     }
-    T *rp = vr.ptr(rbase + s);
+    T *rp = rowp(rbase + s);
     if (rp == nullptr) continue;
     T *dst = rp + c0 + j;
     if constexpr (sizeof(T) == 4) {
@@ -661,6 +665,143 @@ __global__ __launch_bounds__(NTHREADS, NPL ? 2 : 1) void potrf_panel_kernel(VRow
     }
   }
   STAMP(5);
+}
+
+// ---- the rows below an outer block, all four inner blocks in ONE launch (planes route) --------------------------
+// A panel workgroup holds half a CU's LDS for its whole life, and a draw workgroup (b3.hpp: 145 KB) the whole of it:
+// while the factor stream's panel launches run beside the training step, every CU they sit on is lost to the draw,
+// although the panel work is latency-bound and keeps the matrix pipe ~10 % busy.  Four launches per outer block, each
+// with all rows below it, held 0.9 ms of chip time per 16 x 4096 factorisation.  Here the four launches of an outer
+// block cover the rows INSIDE the block only (potrf_panel_kernel with rlim = the block's end: at most two
+// workgroups per matrix; they factor the four 64 x 64 diagonal blocks and park them in dwork), and the rows below the
+// block take ONE launch of this kernel: a workgroup keeps its 128 rows and walks the four inner blocks — copy-in,
+// left-looking update on the planes (its own rows' planes of the earlier inner blocks are its own stores of a moment
+// ago), triangular solve against the parked diagonal block by lane = row sweeps (no factorisation to wait for: the
+// four windows run back to back), stores — without the three launch boundaries and without re-factoring the diagonal
+// block in every workgroup.
+template <int NPL>
+__global__ __launch_bounds__(NTHREADS, 2) void potrf_rows_kernel(float *A, int64_t lda, int64_t strideA, int64_t cJ,
+                                                                 const float *dwork, int64_t npad, B3Out o3) {
+  using T = float;
+  using M = Mfma<float>;
+  constexpr int NCH = 2, S = PanelCfg<float>::S, VPR = NB / 4;
+  using V = float4;
+  __shared__ __align__(16) T Dm[NB * S];
+  __shared__ __align__(16) T Cw[NCH * NB * S];
+  __shared__ T rdiag[NB];
+  __shared__ __align__(16) unsigned char pst[PanelB3<NPL>::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  A += (int64_t)b * strideA;
+  const int64_t rbase = cJ + NBO + (int64_t)blockIdx.x * NB * NCH;  // whole workgroups of real rows (n % 256 == 0)
+  int zoff;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  float sc = 1.0f, sc2 = 1.0f, isc2 = 1.0f;  // fp16 x 2: the planes hold L * scale
+  if constexpr (NPL == 2) {
+    sc = o3.scale[b];
+    const float is = 1.0f / sc;
+    sc2 = sc * sc;
+    isc2 = is * is;
+  }
+  for (int ib = 0; ib < NBO / NB; ++ib) {
+    const int64_t c0 = cJ + (int64_t)ib * NB;
+    PanelB3<NPL> pl;
+    if (ib > 0) {  // plane fragments of the first block of earlier columns, ahead of the copy-in
+      pl.init(o3, b, rbase + wave * 32, c0, cJ, tid);
+      pl.prologue();
+    }
+    {  // the parked diagonal block and this workgroup's rows of the inner block -> LDS
+      // (requesting the next inner block's copy-in ahead of the solve was measured: the launch took 110-125 us
+      // instead of 75-88)
+      const T *l11 = dwork + ((int64_t)b * (npad / NB) + c0 / NB) * (NB * NB);
+      V td[NB * VPR / NTHREADS], tc[NCH * NB * VPR / NTHREADS];
+#pragma unroll
+      for (int p = 0; p < NB * VPR / NTHREADS; ++p) {
+        const int v = tid + p * NTHREADS;
+        td[p] = *reinterpret_cast<const V *>(l11 + (v / VPR) * NB + (v % VPR) * 4);
+      }
+#pragma unroll
+      for (int p = 0; p < NCH * NB * VPR / NTHREADS; ++p) {
+        const int v = tid + p * NTHREADS;
+        tc[p] = *reinterpret_cast<const V *>(A + (rbase + v / VPR) * lda + c0 + (v % VPR) * 4);
+      }
+#pragma unroll
+      for (int p = 0; p < NB * VPR / NTHREADS; ++p) {
+        const int v = tid + p * NTHREADS;
+        *reinterpret_cast<V *>(&Dm[(v / VPR) * S + (v % VPR) * 4]) = td[p];
+      }
+#pragma unroll
+      for (int p = 0; p < NCH * NB * VPR / NTHREADS; ++p) {
+        const int v = tid + p * NTHREADS;
+        *reinterpret_cast<V *>(&Cw[(v / VPR) * S + (v % VPR) * 4]) = tc[p];
+      }
+    }
+    __syncthreads();
+    if (tid < NB) {  // 1 / L_jj, refined (the solve divides as the factorisation does: div_scaled)
+      const T ljj = Dm[tid * S + tid];
+      T y = __builtin_amdgcn_rcpf(ljj);
+      y = fma(fma(-ljj, y, T(1)), y, y);
+      rdiag[tid] = fma(fma(-ljj, y, T(1)), y, y);
+    }
+    if (ib > 0) {  // C -= Pc Pd^T over the block's earlier columns (accumulators start from -C, as everywhere)
+      f32x16 accC[2], accD;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accD[r] = 0.0f;
+        const int ci = wave * 32 + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) accC[fn][r] = -Cw[ci * S + fn * 32 + M::col(lane)] * sc2;
+      }
+      pl.template run<false>(pst, ib, accC, accD, wu >> 1, wu & 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = wave * 32 + M::row(lane, r);
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) Cw[ci * S + fn * 32 + M::col(lane)] = -accC[fn][r] * isc2;
+      }
+    }
+    __syncthreads();
+    if (wave < NCH) {  // X L11^T = C: one 64-row chunk per wave, four 16-column windows back to back
+      T *chunk = &Cw[wave * NB * S];
+#pragma unroll
+      for (int ph = 0; ph < NB / 16; ++ph) window16<T, S, false>(chunk, Dm, rdiag, 16 * ph, lane, zoff, -1);
+    }
+    __syncthreads();
+    // stores: float32 rows and their planes, 8 columns per lane (as potrf_panel_kernel's planes route)
+#pragma unroll 2
+    for (int idx = tid; idx < NCH * NB * 8; idx += NTHREADS) {
+      const int s2 = idx >> 3, j = (idx & 7) * 8;
+      const V t0 = *reinterpret_cast<const V *>(&Cw[s2 * S + j]), t1 = *reinterpret_cast<const V *>(&Cw[s2 * S + j + 4]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = reinterpret_cast<const float *>(&t0)[e];
+        v[4 + e] = reinterpret_cast<const float *>(&t1)[e];
+      }
+      __bf16 *q = o3.p + (int64_t)b * o3.stride + (rbase + s2) * o3.ld + (c0 - o3.col0) + j;
+      if constexpr (NPL == 2) {
+        _Float16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2_f16(v[e] * sc, hh[e], ll[e]);
+        *reinterpret_cast<i32x4_t *>(q) = *reinterpret_cast<const i32x4_t *>(hh);
+        *reinterpret_cast<i32x4_t *>(q + o3.plane) = *reinterpret_cast<const i32x4_t *>(ll);
+      } else {
+        __bf16 hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3_bf16(v[e], hh[e], mm[e], ll[e]);
+        *reinterpret_cast<i32x4_t *>(q) = *reinterpret_cast<const i32x4_t *>(hh);
+        *reinterpret_cast<i32x4_t *>(q + o3.plane) = *reinterpret_cast<const i32x4_t *>(mm);
+        *reinterpret_cast<i32x4_t *>(q + 2 * o3.plane) = *reinterpret_cast<const i32x4_t *>(ll);
+      }
+      T *rp = A + (rbase + s2) * lda + c0 + j;
+      *reinterpret_cast<V *>(rp) = t0;
+      *reinterpret_cast<V *>(rp + 4) = t1;
+    }
+    // the next inner block's left-looking update reads these planes back: the stores are complete (and the LDS
+    // images free) once every wave has passed the barrier
+    __syncthreads();
+  }
 }
 
 // ---- outer trailing update: C[r][c] -= sum_{k in [cJ, cJ+kb)} P[r][k] P[c][k] ----------------------
@@ -1048,6 +1189,13 @@ static inline int64_t cu_count() {
   return v;
 }
 
+// workgroups of rows below an outer block from which potrf_rows_kernel takes them (GPVAE_POTRF_ROWS_MIN in the
+// environment overrides: measurements)
+static inline int64_t rows_split_min() {
+  static const int64_t v = [] { const char *e = getenv("GPVAE_POTRF_ROWS_MIN"); return e ? atoll(e) : (int64_t)128; }();
+  return v;
+}
+
 // workspace: [parked diagonal blocks | bf16 planes of the current outer panel (b3 path only)]
 static inline int64_t l11_bytes(int64_t es, int64_t n, int batch) {
   return round_up((int64_t)batch * round_up(n, NB) * NB * es, 256);
@@ -1085,17 +1233,23 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
     const int jj = (int)((cJ / NBO) % D);          // position in the group of D outer blocks (b3 path)
     const int64_t cP = cJ - (int64_t)jj * NBO;     // first column of the group
     if (b3 && !o3.whole) o3.col0 = cP;
+    // planes route: with enough rows below the outer block to hold a good part of the chip, the four launches cover
+    // the block's own rows only and ONE potrf_rows_kernel launch the rows below it
+    const int64_t rows_wgs = (n - kend) / (NB * NCH) * batch;
+    const bool split = b3 && (flags & GPVAE_POTRF_SHARE_CHIP) && kend - cJ == NBO && rows_wgs >= rows_split_min();
+    const int64_t rlim = split ? kend : INT64_MAX;
     for (int64_t c0 = cJ; c0 < kend; c0 += NB) {
-      const int64_t below = Mv - (c0 + NB);
+      const int64_t mvl = split ? kend : Mv;
+      const int64_t below = mvl - (c0 + NB);
       const int64_t nwg = below > 0 ? cdiv(below, (int64_t)NB * NCH) : 1;
       if constexpr (sizeof(T) == 4 && VECM) {
         if (b3) {
           if (o3.np == 2)
             hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 2>), dim3((unsigned)nwg, (unsigned)batch),
-                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps, rlim);
           else
             hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 3>), dim3((unsigned)nwg, (unsigned)batch),
-                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+                               dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps, rlim);
           continue;
         }
       }
@@ -1104,13 +1258,24 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
         const int64_t nwg3 = below > 0 ? cdiv(below, (int64_t)NB * 3) : 1;
         if (cdiv(nwg3 * batch, ncu) < cdiv(nwg * batch, ncu)) {
           hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 0, 3>), dim3((unsigned)nwg3, (unsigned)batch),
-                             dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps);
+                             dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work, o3, g_stamps, rlim);
           continue;
         }
       }
       hipLaunchKernelGGL((potrf_panel_kernel<T, VECM, 0>), dim3((unsigned)nwg, (unsigned)batch),
                          dim3(NTHREADS), 0, st, vr, strideA, strideX, c0, cJ, info, (T *)work,
-                         o3, g_stamps);
+                         o3, g_stamps, rlim);
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (split) {
+        const dim3 grid((unsigned)((n - kend) / (NB * NCH)), (unsigned)batch);
+        if (o3.np == 2)
+          hipLaunchKernelGGL((potrf_rows_kernel<2>), grid, dim3(NTHREADS), 0, st, (float *)A, lda, strideA, cJ,
+                             (const float *)work, vr.npad, o3);
+        else
+          hipLaunchKernelGGL((potrf_rows_kernel<3>), grid, dim3(NTHREADS), 0, st, (float *)A, lda, strideA, cJ,
+                             (const float *)work, vr.npad, o3);
+      }
     }
     if constexpr (sizeof(T) == 4) {
       if (b3 && kend < n) {
@@ -1145,10 +1310,11 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
                          vr, strideA, strideX, cP, kend, map);
     }
   }
+  const int fflags = flags & (GPVAE_POTRF_ZERO_UPPER | GPVAE_POTRF_NAN_ON_FAIL);  // what the finalize pass acts on
   hipLaunchKernelGGL((potrf_finalize_kernel<T>),
-                     dim3(flags ? (unsigned)cdiv(n, 256) : 1u, (unsigned)cdiv(n, NB), (unsigned)batch),
-                     flags ? dim3(256) : dim3(NB, 4), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
-                     flags, o3);
+                     dim3(fflags ? (unsigned)cdiv(n, 256) : 1u, (unsigned)cdiv(n, NB), (unsigned)batch),
+                     fflags ? dim3(256) : dim3(NB, 4), 0, st, (T *)A, lda, strideA, n, vr.npad, (const T *)work, info,
+                     fflags, o3);
   GPVAE_CHECK_LAUNCH("gpvae_potrf");
   return 0;
 }

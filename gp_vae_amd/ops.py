@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F32, F64, GpvaeError, POTRF_NAN_ON_FAIL, POTRF_ZERO_UPPER, check
+from ._lib import F32, F64, GpvaeError, POTRF_NAN_ON_FAIL, POTRF_SHARE_CHIP, POTRF_ZERO_UPPER, check
 
 _DT = {torch.float32: F32, torch.float64: F64}
 
@@ -97,7 +97,7 @@ def gram_agg(pts, var, ls, jitter=1.0e-6):
     return K
 
 
-def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None):
+def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None, share_chip=False):
     """In-place lower Cholesky of A [n,n] or [batch,n,n]; X ([.., m, n]) becomes X L^-T.
 
     Returns the int32 info tensor [batch] (device; 0 = ok, j = leading minor j not PD)."""
@@ -114,7 +114,8 @@ def potrf_(A, X=None, zero_upper=True, nan_on_fail=True, work=None):
             raise GpvaeError("X must be [batch,m,n], same dtype, unit column stride")
         m = X3.shape[1]
     info = torch.empty((batch,), dtype=torch.int32, device=A.device)
-    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    flags = ((POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+             | (POTRF_SHARE_CHIP if share_chip else 0))  # share_chip: a hint for calls that run beside other work
     lib = _lib.load()
     if work is None:
         work = torch.empty(max(16, lib.gpvae_potrf_workspace_bytes(_dt(A), n, m, batch)),
@@ -341,7 +342,7 @@ def potrf_b3_supported(n):
     return bool(_lib.load().gpvae_potrf_b3_supported(int(n)))
 
 
-def potrf_b3_(A, L3=None, zero_upper=False, nan_on_fail=False, work=None, info=None):
+def potrf_b3_(A, L3=None, zero_upper=False, nan_on_fail=False, work=None, info=None, share_chip=False):
     """In-place float32 Cholesky of A [batch,n,n] (or [n,n]) that also leaves the factor as bf16 x 3 planes
     L3 [batch,3,n,n] for draw_b3 (written by the panel launches themselves: no split pass).
     Returns (info, L3)."""
@@ -358,13 +359,14 @@ def potrf_b3_(A, L3=None, zero_upper=False, nan_on_fail=False, work=None, info=N
     lib = _lib.load()
     if work is None:
         work = torch.empty(max(16, lib.gpvae_potrf_b3_workspace_bytes(n, batch)), dtype=torch.uint8, device=A.device)
-    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    flags = ((POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+             | (POTRF_SHARE_CHIP if share_chip else 0))  # share_chip: a hint for calls that run beside other work
     check(lib.gpvae_potrf_b3(_stream(), n, batch, _p(A3), A3.stride(1), A3.stride(0), _p(info), flags, _p(work),
                              _p(o), o.stride(2), o.stride(1), o.stride(0)), "gpvae_potrf_b3")
     return info, (o if A.dim() == 3 else o[0])
 
 
-def potrf_h2_(A, L2=None, inv_scale=None, zero_upper=False, nan_on_fail=False, work=None, info=None):
+def potrf_h2_(A, L2=None, inv_scale=None, zero_upper=False, nan_on_fail=False, work=None, info=None, share_chip=False):
     """potrf_b3_ with the factor left as fp16 x 2 planes L2 [batch,2,n,n] of L * 2^e_b for draw_h2 and the trailing
     updates on those planes; inv_scale [batch] float32 = 2^-e_b.  Returns (info, L2, inv_scale)."""
     _dev(A, L2, inv_scale)
@@ -382,7 +384,8 @@ def potrf_h2_(A, L2=None, inv_scale=None, zero_upper=False, nan_on_fail=False, w
     lib = _lib.load()
     if work is None:
         work = torch.empty(max(16, lib.gpvae_potrf_h2_workspace_bytes(n, batch)), dtype=torch.uint8, device=A.device)
-    flags = (POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+    flags = ((POTRF_ZERO_UPPER if zero_upper else 0) | (POTRF_NAN_ON_FAIL if nan_on_fail else 0)
+             | (POTRF_SHARE_CHIP if share_chip else 0))  # share_chip: a hint for calls that run beside other work
     check(lib.gpvae_potrf_h2(_stream(), n, batch, _p(A3), A3.stride(1), A3.stride(0), _p(info), flags, _p(work),
                              _p(o), o.stride(2), o.stride(1), o.stride(0), _p(inv_scale)), "gpvae_potrf_h2")
     return info, (o if A.dim() == 3 else o[0]), inv_scale

@@ -424,8 +424,10 @@ class StepEngine():
         self._h_main = vp(self._main.cuda_stream)
 
     # -- stage A: the factors of one group of steps (own stream) ---------------------------------------
-    def _issue_factors(self, keys, slot):
+    def _issue_factors(self, keys, slot, share_chip=False):
+        """share_chip: the group is factored beside the steps of the group before it (GPVAE_POTRF_SHARE_CHIP = 4)."""
         g = len(keys)
+        pflags = 4 if share_chip else 0
         device_hyper = isinstance(self.hyper_sampler, str)
         if not device_hyper:
             pin = self.hyper_pin[slot]
@@ -463,15 +465,15 @@ class StepEngine():
             # the draw masks the strict upper triangle itself: no zeroing / NaN-fill pass needed
             if self.b3:  # factor + its bf16 planes in one sweep (the panel launches write the planes)
                 check(lib.gpvae_potrf_b3(_stream(), self.n, g, _p(K), self.ld, self.n * self.ld, _p(self.info[slot]),
-                                         0, _p(self.pwork[slot]), _p(self.L3buf[slot]), self.n, self.n * self.n,
+                                         pflags, _p(self.pwork[slot]), _p(self.L3buf[slot]), self.n, self.n * self.n,
                                          3 * self.n * self.n), "gpvae_potrf_b3")
             elif self.h2:  # the same with fp16 x 2 planes of L * 2^e, e from the largest diagonal entry
                 check(lib.gpvae_potrf_h2(_stream(), self.n, g, _p(K), self.ld, self.n * self.ld, _p(self.info[slot]),
-                                         0, _p(self.pwork[slot]), _p(self.L2buf[slot]), self.n, self.n * self.n,
+                                         pflags, _p(self.pwork[slot]), _p(self.L2buf[slot]), self.n, self.n * self.n,
                                          2 * self.n * self.n, _p(self.L2inv[slot])), "gpvae_potrf_h2")
             else:
                 check(lib.gpvae_potrf(_stream(), _dt(K), self.n, g, _p(K), self.ld, self.n * self.ld,
-                                      0, C.c_void_p(0), 0, 0, _p(self.info[slot]), 0, _p(self.pwork[slot])),
+                                      0, C.c_void_p(0), 0, 0, _p(self.info[slot]), pflags, _p(self.pwork[slot])),
                       "gpvae_potrf")
             self.info_fail.add_(self.info[slot][:g].ne(0).sum().to(torch.int32))
             self.ev_ready[slot].record(stream)
@@ -659,8 +661,8 @@ class StepEngine():
         t = 0
         for gi, grp in enumerate(groups):
             slot = gi & 1
-            if gi + 1 < len(groups):
-                self._issue_factors(groups[gi + 1], (gi + 1) & 1)
+            if gi + 1 < len(groups):  # factored beside this group's steps: the first group of a run has the chip to itself
+                self._issue_factors(groups[gi + 1], (gi + 1) & 1, share_chip=self.overlap)
             for i, key in enumerate(grp):
                 # the next group's normals go out half a group after its factors, so that the two bursts of
                 # side-stream work do not fall on the same steps (measured: no difference to the step, 0.768-0.774 ms

@@ -42,7 +42,14 @@ enum { GPVAE_F32 = 0, GPVAE_F64 = 1 };
 /* gpvae_potrf flags */
 enum {
   GPVAE_POTRF_ZERO_UPPER = 1, /* clear the strict upper triangle (JAX returns a clean lower factor) */
-  GPVAE_POTRF_NAN_ON_FAIL = 2 /* a non-PD matrix comes back all-NaN (jnp.linalg.cholesky semantics) */
+  GPVAE_POTRF_NAN_ON_FAIL = 2, /* a non-PD matrix comes back all-NaN (jnp.linalg.cholesky semantics) */
+  /* A hint, not a change of result: the call runs beside other work on the GPU (the training loop's factor stream
+   * beside draws and ELBO).  The bf16-plane route then holds fewer CUs: per 256-column outer block the four panel
+   * launches cover the block's own rows only (at most two workgroups per matrix) and ONE launch takes all rows
+   * below it through the four 64-column steps (potrf.hip potrf_rows_kernel) — about half the chip time the panel
+   * workgroups' LDS keeps from a co-running kernel, for a dependent chain that is ~8 % longer when the call runs
+   * alone (16 x 4096: 4.1 -> 4.45 ms alone; the training step 0.780 -> 0.771 ms).  No effect on other routes. */
+  GPVAE_POTRF_SHARE_CHIP = 4
 };
 
 int gpvae_abi_version(void);

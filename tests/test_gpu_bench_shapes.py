@@ -35,11 +35,13 @@ LS_LADDER = (0.02, 0.05, 0.3, 1.1, 4.4, 55.0, 1.0e3)
 LS_REST = (0.01, 0.1, 0.144, 0.6, 2.0, 13.954, 200.0, 1.0e4, 0.2)
 
 
-def test_potrf_b3_c3_factor_group_on_the_priors_gram_matrices():
+@pytest.mark.parametrize("share_chip", [False, True])
+def test_potrf_b3_c3_factor_group_on_the_priors_gram_matrices(share_chip):
     """gpvae_potrf_b3, n = 4096, batch 16 (the training factor group), jitter 1e-3, length scales over the prior's
     whole range: info == 0; backward error max |L L^T - K| within 3x LAPACK spotrf's on the same float32 matrix;
     the bf16 planes ARE tril(L) bit for bit; the factor against the float64 oracle under the float32 bar; draws
-    from the planes against a float64 product."""
+    from the planes against a float64 product.  share_chip: the form the training loop's factor stream asks for
+    (GPVAE_POTRF_SHARE_CHIP: the rows below an outer block in one potrf_rows_kernel launch)."""
     from gp_vae_amd import ops
     n, batch, jit = 4096, 16, 1e-3
     xh = grid2(64)
@@ -50,7 +52,7 @@ def test_potrf_b3_c3_factor_group_on_the_priors_gram_matrices():
                     torch.tensor(ls, dtype=torch.float32, device=DEV), jit).reshape(batch, n, n)
     A = K.clone()
     junk = torch.full((batch, 3, n, n), 7.0, dtype=torch.bfloat16, device=DEV)
-    info, L3 = ops.potrf_b3_(A, junk)
+    info, L3 = ops.potrf_b3_(A, junk, share_chip=share_chip)
     assert info.cpu().tolist() == [0] * batch
     E3 = ops.randn_b3((512, n), DEV, seed=11, stream_id=3)
     E = E3.float().sum(0)

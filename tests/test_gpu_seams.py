@@ -420,6 +420,45 @@ def test_potrf_b3_factor_and_planes():
         assert not torch.isnan(ops.draw_b3(L32[0], ops.randn_b3((256, n), DEV, seed=1))).any()
 
 
+def test_potrf_share_chip_rows_kernel():
+    """GPVAE_POTRF_SHARE_CHIP (the factor stream's calls in StepEngine): per outer block the panel launches cover the
+    block's own rows and ONE potrf_rows_kernel launch the rows below it (n = 1024 x 48 matrices: the first two outer
+    blocks take that form, the rest the plain one).  A hint, not a change of result: same info, the factor of the
+    plain call to rounding (the solve's reciprocals come from another seed), planes == factor bit for bit, LAPACK-level
+    backward error, on the three entry points of the planes route."""
+    from gp_vae_amd import ops
+    rng = np.random.default_rng(11)
+    n, batch = 1024, 48
+    x = torch.tensor(rng.random((n, 2)), dtype=torch.float32, device=DEV)
+    ls = torch.linspace(0.04, 3.0, batch, device=DEV)  # up to nearly rank-one matrices
+    K = ops.gram_se(x, x, torch.ones(batch, device=DEV), ls, 1e-3).reshape(batch, n, n)
+    K[5, 700, 700] = -1.0  # not positive definite from column 701
+    want_info = [0] * batch
+    want_info[5] = 701
+    ref = K.clone()
+    assert ops.potrf_(ref, zero_upper=False, nan_on_fail=False).cpu().tolist() == want_info
+    A0 = K.clone()
+    assert ops.potrf_(A0, zero_upper=False, nan_on_fail=False, share_chip=True).cpu().tolist() == want_info
+    A1 = K.clone()
+    info1, L3 = ops.potrf_b3_(A1, share_chip=True)
+    A2 = K.clone()
+    info2, L2, inv2 = ops.potrf_h2_(A2, share_chip=True)
+    assert info1.cpu().tolist() == want_info and info2.cpu().tolist() == want_info
+    ok = [b for b in range(batch) if b != 5]  # (the failed matrix holds NaN from column 701 on)
+    assert torch.equal(A0[ok].tril(), A1[ok].tril())  # workspace planes and the caller's planes: the same arithmetic
+    for b in (0, 17, 47):
+        Kb = K[b].double()
+        for A in (A1, A2):
+            L = torch.tril(A[b]).double()
+            assert (torch.linalg.norm(L @ L.T - Kb) / torch.linalg.norm(Kb)).item() < 2e-6
+        d = (A1[b].tril() - ref[b].tril()).abs().max().item()
+        assert d <= 4e-6 * ref[b].abs().max().item(), d
+        dif = (torch.tril(L3[b].float().sum(0)) - torch.tril(A1[b])).abs()
+        assert dif.max().item() < 1e-30
+        Lh = (L2[b].float().sum(0) * inv2[b]).tril()
+        assert rel(Lh, A2[b].tril().cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("tdt,tol", [(torch.float64, 1e-12), (torch.float32, 2e-7)])
 def test_device_hyper_prior_samplers(tdt, tol):
     """gpvae_hyper_sample against the oracle's restatement (same Philox words, same Marsaglia-Tsang
