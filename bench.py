@@ -39,8 +39,9 @@ PEAK_F64_MFMA_TFLOPS = 78.6   # dense f64 matrix peak
 PEAK_HBM_GBS = 8000.0         # HBM3E, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 # what v_mfma_f32_32x32x16_bf16 sustains on this chip with random operand bits and no memory traffic at all
-# (tools/ub_mfma_power.hip, profiles/r02_mfma_power.txt; 2.46 PFLOP/s with constant operands): power management
-SUSTAINED_BF16_MFMA_RANDOM_TFLOPS = 1810.0
+# (tools/ub_mfma_power.hip; 2.45 PFLOP/s with constant operands): power management.  1.81 PFLOP/s on the round-2 box
+# (profiles/r02_mfma_power.txt), 1.90 on the round-3 one (profiles/r03_mfma_shape_power.txt): devices differ
+SUSTAINED_BF16_MFMA_RANDOM_TFLOPS = 1900.0
 GRID = 64
 N = GRID * GRID
 B = 4096
@@ -105,9 +106,9 @@ def cpu_baseline(steps=12, budget_s=12.0):
 def pmc_traffic(b3):
     """HBM bytes per draw launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of tools/prof_draw.py at this shape, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950): profiles/r02_draw_b3_pmc.json for the bf16 x 3 kernel, r01_draw_pmc.json for
+    prescribes for gfx950): profiles/r03_draw_b3_pmc.json for the bf16 x 3 kernel, r01_draw_pmc.json for
     the f32-MFMA kernel.  bench.py cannot collect counters itself; null when no pass is committed."""
-    name = "r02_draw_b3_pmc.json" if b3 else "r01_draw_pmc.json"
+    name = "r03_draw_b3_pmc.json" if b3 else "r01_draw_pmc.json"
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         with open(path) as f:
