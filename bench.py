@@ -474,6 +474,10 @@ def main():
             roof["frac_of_mfma_only_sustained"] = 6 * f32_equiv / SUSTAINED_BF16_MFMA_RANDOM_TFLOPS if f32_equiv else None
             roof["launches_timed"] = "%d of %d (every launch number divisible by %d in the timed region, HIP events on its stream)" % (
                 draw_timed, args.steps, DRAW_EVENTS_EVERY)
+            roof["note"] = ("avg_launch_ms / frac: HIP events around the draw's launches INSIDE the timed steps, where the "
+                            "factor stream's and the normals stream's workgroups hold part of the CUs (a draw workgroup "
+                            "fills a CU's LDS and register file: a CU runs the draw or something else, never both); "
+                            "avg_launch_ms_alone / frac_alone: the same launch with nothing beside it on the chip")
             if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
                 roof["avg_launch_ms_alone"] = draw_alone_ms
                 roof["frac_alone"] = 6 * flop / (draw_alone_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
