@@ -287,6 +287,27 @@ def test_potrf_b3_and_draw_b3_random_shapes(ops):
             assert rel(Y, want.cpu().numpy()) < 1e-6, tag + (b,)
 
 
+def test_potrf_share_chip_random_shapes(ops):
+    """GPVAE_POTRF_SHARE_CHIP over shapes on both sides of its switch (the rows below an outer block go to
+    potrf_rows_kernel from 128 workgroups of rows up: batch x rows / 128), padded leading dimensions included: same
+    info, factor against LAPACK at the bar of the plain call and within rounding of it, planes == factor."""
+    rng = np.random.default_rng(37)
+    for case, (n, batch) in enumerate([(2048, 12), (1024, 40), (1536, 17), (768, 64), (512, 70), (2304, 9)]):
+        A = spd(rng, batch, n)
+        pad = int(rng.choice([0, 4, 12]))
+        Ad, Ap = padded(A, torch.float32, pad), padded(A, torch.float32, pad)
+        info, L3 = ops.potrf_b3_(Ad, share_chip=True)
+        info_p, _ = ops.potrf_b3_(Ap)
+        tag = (case, n, batch, pad)
+        assert (info == 0).all() and (info_p == 0).all(), tag
+        for b in {0, batch // 2, batch - 1}:
+            Lo = np.linalg.cholesky(A[b])
+            Ld = torch.tril(Ad[b])
+            assert rel(Ld, Lo) < 2e-5, tag + (b, rel(Ld, Lo))
+            assert (Ld - torch.tril(Ap[b])).abs().max().item() <= 4e-6 * Ld.abs().max().item(), tag
+            assert torch.equal(torch.tril(L3[b].float().sum(0)), Ld), tag
+
+
 def test_potrf_h2_and_draw_h2_random_shapes(ops):
     """The opt-in fp16 x 2 route over the same shapes, with matrix scales from 1e-3 to 1e3 (the planes' power-of-two
     scale is chosen per matrix from its diagonal): factor against LAPACK, planes == factor * 2^e to 2^-21, draw from
