@@ -16,6 +16,9 @@
 //       its chunks X L11^T = C with the same lane = row sweep, one chunk per wave.
 //       The diagonal block is factored redundantly by every workgroup: that costs no wall time and
 //       removes the launch boundary a separate "diagonal" kernel would need.
+//       With GPVAE_POTRF_SHARE_CHIP (float32 planes route, calls that run beside other kernels) those launches cover
+//       the outer block's own rows only and potrf_rows_kernel takes the rows below it through the four inner
+//       blocks in one launch (half the chip time held, a longer chain).
 // "Virtual rows": rows >= n come from a second array X (m_extra rows of length n); they ride along
 // as extra chunks and come out as X L^-T — the right-hand solve kriging needs — for free.
 // Rows/cols between n and the next multiple of 64 behave as an identity block.
