@@ -114,31 +114,39 @@ def _replay_on_oracle(x, keys, dims, B, lr, jit, seed, p0):
     return total, p, hypers
 
 
-@pytest.mark.parametrize("case", ["C3", "C2"])
+@pytest.mark.parametrize("case", ["C3", "C2", "C3-second-group-beside-steps"])
 def test_step_engine_at_the_benchmarked_shapes_matches_oracle(case):
     """The pipeline bench.py times — factor groups on the side stream (two slots, crossed here: group = 2, 5 steps),
     hyper-priors drawn on the device, Philox normals as bf16 planes, gpvae_potrf_b3 / gpvae_draw_b3, the fused
     ELBO, Adam — end to end against oracle.train_step on identical inputs, at full size.  The epoch keys are picked
-    so that the five steps include a draw from the length-scale prior's tail (ls = 13.95 / 9.13: nearly rank-one K)."""
+    so that the five steps include a draw from the length-scale prior's tail (ls = 13.95 / 9.13: nearly rank-one K).
+    Third case: groups of 6, 12 steps — the second group is factored beside the first group's steps with
+    GPVAE_POTRF_SHARE_CHIP, and 6 matrices are enough for potrf_rows_kernel to take the rows below the first outer
+    blocks (30 workgroups per matrix x 6 >= 128), so the rows kernel, the per-group normal buffers and the slot swap
+    are all on the path that is compared with the oracle."""
     from gp_vae_amd.vae import StepEngine, SVIState
+    group, nsteps = 2, 5
     if case == "C3":
         x, B, dims, jit, ek = grid2(64), 4096, (50, 30, 15), 1e-3, 5
-    else:
+    elif case == "C2":
         x, B, dims, jit, ek = np.arange(0, 1, 1 / 1024), 4096, (35, 30, 10), 1e-4, 35
+    else:
+        x, B, dims, jit, ek, group, nsteps = grid2(64), 4096, (50, 30, 15), 1e-3, 7, 6, 12
     n, lr, seed = x.shape[0], 1e-3, 1
-    keys = [(ek, i) for i in range(5)]
+    keys = [(ek, i) for i in range(nsteps)]
     p0 = {k: 5 * a for k, a in orc.init_params(np.random.default_rng(0), n, *dims, np.float64).items()}
-    eng = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=torch.float32, seed=seed, group=2, hyper_sampler="device")
-    assert eng.b3 and eng.G == 2
+    eng = StepEngine(torch.tensor(x), jit, dims, B, lr, dtype=torch.float32, seed=seed, group=group, hyper_sampler="device")
+    assert eng.b3 and eng.G == group and eng.gn
     st = SVIState(torch.tensor(orc.flatten(p0), dtype=torch.float32, device=DEV))
     got = eng.run(keys, st, train=True).item()
     assert eng.failed_factors() == 0
     steps = eng.loss_steps.cpu().numpy().astype(np.float64)
     want, p, hypers = _replay_on_oracle(x, keys, dims, B, lr, jit, seed, p0)
-    assert max(h[0] for h in hypers) > 5.0 and min(h[0] for h in hypers) < 0.11, hypers  # tail and short scales both in
+    if nsteps == 5:
+        assert max(h[0] for h in hypers) > 5.0 and min(h[0] for h in hypers) < 0.11, hypers  # tail and short scales both in
     assert np.isfinite(steps).all() and abs(steps.sum() - got) < 1e-5 * abs(got)
     print("\n%s: loss %.9g oracle %.9g (rel %.2e), params rel %.2e, ls %s" % (
         case, got, want, abs(got - want) / abs(want), rel(st.params, orc.flatten(p)), [round(h[0], 3) for h in hypers]))
     assert abs(got - want) < 2e-3 * abs(want), (got, want)
     assert rel(st.params, orc.flatten(p)) < 2e-3
-    assert st.t == 5
+    assert st.t == nsteps
