@@ -484,62 +484,70 @@ static inline unsigned ew_blocks(int64_t count) {
 // registers over the walk.  Y is read once, V3 once per row block (L2).
 constexpr int FS = 68;  // LDS row stride of the 64-wide images (16-byte aligned rows)
 
-__global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
+// Eight waves (two per SIMD) since round 3: the kernel is a chain of short MFMA bursts separated by LDS round trips, an
+// epilogue and a barrier, and with one wave per SIMD nothing ran while a wave waited (the products on the bf16 pipe
+// instead, 2.5x cheaper, gained 8 %: profiles/r03_elbo_b3_experiment.txt).  Product 1 is split over all eight waves
+// (32 x 32 tiles of F); after the barrier waves 0-3 run product 3 (one 32 x 32 tile of [dV3; dc3] each, K = 128) and
+// waves 4-7 product 2 (32 rows of dD2 each): 96 MFMAs per wave and tile either way.  Wave roles are scalar values
+// (readfirstlane): an MFMA does not honour EXEC.  Same sums in the same order as the four-wave form.
+constexpr int FUSED_THREADS = 512;
+__global__ __launch_bounds__(FUSED_THREADS) void vae_out_fused_kernel(
     int64_t n, int h0, const float *__restrict__ D2, const float *__restrict__ V3c,
     const float *__restrict__ Y, int64_t ldy, float inv_var, float *lp, float *dD2s, int64_t slabD,
     float *dV3s, int64_t slabV, int nt) {
   using M = Mfma<float>;
+  constexpr int NT = FUSED_THREADS;
   // 153 KB of LDS, one workgroup per CU.  The V3 image is triple- and the DF image double-buffered, so
   // that ONE barrier per tile (DF tile complete / next V3 tile staged) orders everything and product 1
-  // of tile t+1 follows product 3 of tile t in each wave's MFMA stream:
+  // of tile t+1 follows product 2 / 3 of tile t in each wave's MFMA stream:
   //   V3s[(t+1) % 3] is written in tile t; its last readers (product 2 of tile t-2) finished before
   //   the barrier of tile t-1, which every wave has passed; DFs[t & 1] likewise (readers: tile t-2).
   __shared__ __align__(16) float lds[128 * FS + 3 * 64 * FS + 2 * 128 * FS];
   float *D2s = lds;               // [row][k]: D2, a ones column at k = h0, zeros beyond
   float *V3b = D2s + 128 * FS;    // 3 x [k][col]: V3 rows, c3 at k = h0, zeros beyond
   float *DFb = V3b + 3 * 64 * FS; // 2 x [row][col]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7, scalar
   const int64_t row0 = (int64_t)blockIdx.x * 128;
   const int64_t tile0 = (int64_t)blockIdx.y * nt;
   const int64_t ntiles = n / 64;
   const int ntl = (int)((tile0 + nt <= ntiles) ? nt : ntiles - tile0);  // tiles of this workgroup (>= 1)
 
-  for (int idx = tid; idx < 128 * 64; idx += NTHREADS) {
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
     const int r = idx >> 6, k = idx & 63;
     D2s[r * FS + k] = k < h0 ? D2[(row0 + r) * h0 + k] : (k == h0 ? 1.0f : 0.0f);
   }
-  // V3 tile: 64 k-rows x 16 vectors, 4 per thread; rows past h0 lie outside the buffer and read 0
+  // V3 tile: 64 k-rows x 16 vectors, 2 per thread; rows past h0 lie outside the buffer and read 0
   i32x4_t vrs = make_buffer_rsrc(V3c);
   vrs[2] = __builtin_amdgcn_readfirstlane((int)((int64_t)(h0 + 1) * n * 4));
-  int vvo[4];
+  int vvo[2];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int v = tid + p * NTHREADS;
+  for (int p = 0; p < 2; ++p) {
+    const int v = tid + p * NT;
     vvo[p] = (v >> 4) * (int)(n * 4) + (v & 15) * 16;
   }
-  i32x4_t vreg[4];
+  i32x4_t vreg[2];
   auto load_v3 = [&](int64_t tile) {
     const int so = (int)(tile * 64 * 4);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) vreg[p] = raw_buffer_load_b128(vrs, vvo[p], so, 0);
+    for (int p = 0; p < 2; ++p) vreg[p] = raw_buffer_load_b128(vrs, vvo[p], so, 0);
   };
   auto stage_v3 = [&](float *dst) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int v = tid + p * NTHREADS;
+    for (int p = 0; p < 2; ++p) {
+      const int v = tid + p * NT;
       *reinterpret_cast<i32x4_t *>(&dst[(v >> 4) * FS + (v & 15) * 4]) = vreg[p];
     }
   };
-  // data tile of this wave's 32 rows; like the V3 tile it is requested ahead and BEFORE the previous
-  // tile's gradient stores
-  float yv[2][M::NACC];
+  // product 1: wave -> rows 32 (wu >> 1) .., columns 32 (wu & 1) .. of the tile; its data tile is requested a tile
+  // ahead and BEFORE the previous tile's gradient stores
+  const int rb1 = (wu >> 1) * 32, cb1 = (wu & 1) * 32;
+  float yv[M::NACC];
   auto load_y = [&](int64_t tile) {
     TileIO<float> ioy;
-    ioy.init(Y + (row0 + wave * 32) * ldy + tile * 64, ldy, lane);
+    ioy.init(Y + (row0 + rb1) * ldy + tile * 64 + cb1, ldy, lane);
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int r = 0; r < M::NACC; ++r) yv[fn][r] = ioy.load(0, fn, r);
+    for (int r = 0; r < M::NACC; ++r) yv[r] = ioy.load(0, 0, r);
   };
   load_v3(tile0);
   stage_v3(V3b);
@@ -547,54 +555,62 @@ __global__ __launch_bounds__(NTHREADS) void vae_out_fused_kernel(
   if (ntl > 1) load_v3(tile0 + 1);
   __syncthreads();  // D2s and the first V3 tile staged
 
-  typename M::acc_t acc2[1][2];  // dD2 rows of this wave x (h0 padded to 64), over the whole walk
+  typename M::acc_t acc2[1][2];  // waves 4-7: dD2 rows 32 (wu - 4) .. x (h0 padded to 64), over the whole walk
   zero_acc<float, 1, 2>(acc2);
   float lsum = 0.0f;
-  const int wm3 = (wave >> 1) * 32, wn3 = (wave & 1) * 32;  // product 3: (h0 index, column) quadrant
+  const int wm3 = ((wu & 3) >> 1) * 32, wn3 = (wu & 1) * 32;  // waves 0-3, product 3: (h0 index, column) quadrant
 
   for (int t = 0; t < ntl; ++t) {
     const int64_t col0 = (tile0 + t) * 64;
     const float *V3s = V3b + (t % 3) * 64 * FS;
     float *DFs = DFb + (t & 1) * 128 * FS;
-    typename M::acc_t acc1[1][2];
-    zero_acc<float, 1, 2>(acc1);
-    mma_ktile<float, 1, 2, 64, true, FS, false, FS>(D2s, V3s, wave * 32, 0, lane, acc1);
+    typename M::acc_t acc1[1][1];
+    zero_acc<float, 1, 1>(acc1);
+    mma_ktile<float, 1, 1, 64, true, FS, false, FS>(D2s, V3s, rb1, cb1, lane, acc1);
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
-#pragma unroll
-      for (int r = 0; r < M::NACC; ++r) {
-        const float diff = acc1[0][fn][r] - yv[fn][r];
-        lsum += diff * diff;
-        DFs[(wave * 32 + M::row(lane, r)) * FS + fn * 32 + M::col(lane)] = diff * inv_var;
-      }
+    for (int r = 0; r < M::NACC; ++r) {
+      const float diff = acc1[0][0][r] - yv[r];
+      lsum += diff * diff;
+      DFs[(rb1 + M::row(lane, r)) * FS + cb1 + M::col(lane)] = diff * inv_var;
+    }
     if (t + 1 < ntl) {  // next tile's operands, ahead of this tile's gradient stores
       stage_v3(V3b + ((t + 1) % 3) * 64 * FS);
       load_y(tile0 + t + 1);
       if (t + 2 < ntl) load_v3(tile0 + t + 2);
     }
     __syncthreads();  // DF tile complete, next V3 tile staged
-    mma_ktile<float, 1, 2, 64, true, FS, true, FS>(DFs, V3s, wave * 32, 0, lane, acc2);  // dD2 += DF V3^T
-    typename M::acc_t acc3[1][1];  // [dV3; dc3] tile: K = the 128 rows
-    zero_acc<float, 1, 1>(acc3);
-    mma_ktile<float, 1, 1, 128, false, FS, false, FS>(D2s, DFs, wm3, wn3, lane, acc3);
+    if (wu >= 4) {
+      mma_ktile<float, 1, 2, 64, true, FS, true, FS>(DFs, V3s, (wu - 4) * 32, 0, lane, acc2);  // dD2 += DF V3^T
+    } else {
+      typename M::acc_t acc3[1][1];  // [dV3; dc3] tile: K = the 128 rows
+      zero_acc<float, 1, 1>(acc3);
+      // (two halves of K: all 128 k values' fragments at once do not fit beside the other role's registers)
+      mma_ktile<float, 1, 1, 64, false, FS, false, FS>(D2s, DFs, wm3, wn3, lane, acc3);
+      mma_ktile<float, 1, 1, 64, false, FS, false, FS>(D2s + 64 * FS, DFs + 64 * FS, wm3, wn3, lane, acc3);
 #pragma unroll
-    for (int r = 0; r < M::NACC; ++r) {
-      const int hi = wm3 + M::row(lane, r);
-      if (hi <= h0) dV3s[(int64_t)blockIdx.x * slabV + (int64_t)hi * n + col0 + wn3 + M::col(lane)] = acc3[0][0][r];
+      for (int r = 0; r < M::NACC; ++r) {
+        const int hi = wm3 + M::row(lane, r);
+        if (hi <= h0) dV3s[(int64_t)blockIdx.x * slabV + (int64_t)hi * n + col0 + wn3 + M::col(lane)] = acc3[0][0][r];
+      }
     }
   }
+  if (wu >= 4) {
 #pragma unroll
-  for (int fn = 0; fn < 2; ++fn)
+    for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
-    for (int r = 0; r < M::NACC; ++r) {
-      const int hi = fn * 32 + M::col(lane);
-      if (hi < h0) dD2s[(int64_t)blockIdx.y * slabD + (row0 + wave * 32 + M::row(lane, r)) * h0 + hi] = acc2[0][fn][r];
-    }
-  __shared__ float red[4];
+      for (int r = 0; r < M::NACC; ++r) {
+        const int hi = fn * 32 + M::col(lane);
+        if (hi < h0) dD2s[(int64_t)blockIdx.y * slabD + (row0 + (wu - 4) * 32 + M::row(lane, r)) * h0 + hi] = acc2[0][fn][r];
+      }
+  }
+  __shared__ float red[8];
   lsum = wave_sum<float>(lsum);
-  if (lane == 0) red[wave] = lsum;
+  if (lane == 0) red[wu] = lsum;
   __syncthreads();
-  if (tid == 0) lp[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.5f * inv_var * ((red[0] + red[1]) + (red[2] + red[3]));
+  // (row block, column half) pairs summed first: the four-wave form's per-wave partial sums, in its order
+  if (tid == 0)
+    lp[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] =
+        0.5f * inv_var * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
 }
 
 // ---- Adam (jax.experimental.optimizers.adam, as numpyro.optim.Adam wraps it) ------------------------
@@ -825,7 +841,7 @@ static int run_vae_elbo(hipStream_t st, int64_t B, int64_t n, int h0, int h1, in
   if constexpr (sizeof(T) == 4) fused = grads != nullptr && pl.fused_dims && 32 * ldy * 4 < ((int64_t)1 << 31);
   if (fused) {
     if constexpr (sizeof(T) == 4) {
-      hipLaunchKernelGGL(vae_out_fused_kernel, dim3((unsigned)pl.fgx, (unsigned)pl.fgy), dim3(NTHREADS), 0, st, n,
+      hipLaunchKernelGGL(vae_out_fused_kernel, dim3((unsigned)pl.fgx, (unsigned)pl.fgy), dim3(FUSED_THREADS), 0, st, n,
                          h0, W.D2, P.V3, Y, ldy, inv_var, W.LP + nlp, W.SD2, slabH, W.SV3, slabV, pl.nt);
       nlp += pl.fgx * pl.fgy;
       nsV = (int)pl.fgx;
