@@ -118,16 +118,16 @@ __global__ __launch_bounds__(256) void randn_h2_kernel(int64_t count, uint64_t s
   }
 }
 
-// One workgroup per 256 x 128 (WFM = 4) or 128 x 128 (WFM = 2) tile of Y, heaviest column tiles first (their k
-// range grows with the column index), plain round-robin placement over the XCDs as in draw_kernel.
+// One workgroup per 256 x 128 (eight waves of 64 x 64) or 128 x 128 (four waves) tile of Y, heaviest column tiles first
+// (their k range grows with the column index), plain round-robin placement over the XCDs as in draw_kernel.
 // NP = 2 (fp16 x 2): the planes hold scaled operands; the accumulators are multiplied by scale_p[0] * escale
 // (powers of two: exact) before the epilogue.
-template <int WFM, int NP>
-__global__ __launch_bounds__(NTHREADS, 1) void draw_b3_kernel(
+template <int WFM, int NP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void draw_b3_kernel(
     int n, int nb, const uint16_t *L3, int64_t ldl, int64_t planeL, const uint16_t *E3, int64_t lde,
     int64_t planeE, const float *E2, int64_t lde2, const float *sigma_p, float *F, int64_t ldf,
     float *Y, int64_t ldy, const float *scale_p, float escale) {
-  using Pipe = PipeB3T<WFM, NP>;
+  using Pipe = PipeB3T<WFM, NP, NW>;
   __shared__ __align__(16) unsigned char lds[Pipe::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nrt = nb / Pipe::TM, nct = n / B3_TN;
@@ -258,8 +258,8 @@ extern "C" int gpvae_draw_b3(void *stream, int64_t n, int64_t nb, const void *L3
                        (int)nb, (const uint16_t *)L3, ldl, planeL, (const uint16_t *)E3, lde, planeE,
                        (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy,
                        (const float *)nullptr, 1.0f);
-  else
-    hipLaunchKernelGGL((draw_b3_kernel<4, 3>), dim3((unsigned)grid), dim3(NTHREADS), 0, (hipStream_t)stream, (int)n,
+  else  // 256 x 128 tiles on eight waves
+    hipLaunchKernelGGL((draw_b3_kernel<2, 3, 8>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (int)n,
                        (int)nb, (const uint16_t *)L3, ldl, planeL, (const uint16_t *)E3, lde, planeE,
                        (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy,
                        (const float *)nullptr, 1.0f);
@@ -340,7 +340,7 @@ extern "C" int gpvae_draw_h2(void *stream, int64_t n, int64_t nb, const void *L2
                        (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy,
                        (const float *)inv_scale_L, 1.0f / H2_E_SCALE);
   else
-    hipLaunchKernelGGL((draw_b3_kernel<4, 2>), dim3((unsigned)grid), dim3(NTHREADS), 0, (hipStream_t)stream, (int)n,
+    hipLaunchKernelGGL((draw_b3_kernel<2, 2, 8>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (int)n,
                        (int)nb, (const uint16_t *)L2, ldl, planeL, (const uint16_t *)E2h, lde, planeE,
                        (const float *)E2, lde2, (const float *)sigma, (float *)F, ldf, (float *)Y, ldy,
                        (const float *)inv_scale_L, 1.0f / H2_E_SCALE);

@@ -10,9 +10,14 @@
 // in the k loop costs ~100 vector-ALU instructions per k-tile and thread, and vector work adds to
 // MFMA time on this chip: gemm_core.hpp).
 //
-// PipeB3: C (256 x 128 per 256-thread workgroup, 4 waves as 2 x 2, each 128 x 64) += A B^T with both
-// operands K-contiguous (rows of length >= K), one workgroup per CU (145.5 KB of LDS, 512 registers
-// per lane).  Software pipeline inside each wave (measured levers in tools/proto_draw_b3p.hip):
+// PipeB3T<WFM, NP, NW>: C ((32 WFM NW / 2) x 128 per workgroup of NW waves, NW / 2 along M x 2 along N, each wave
+// (32 WFM) x 64) += A B^T with both operands K-contiguous (rows of length >= K), one workgroup per CU.  The 256 x 128
+// tile of the draw and the trailing update runs on EIGHT waves of 64 x 64 (WFM = 2, NW = 8: 145.5 KB of LDS, ~210
+// registers per lane, two waves per SIMD) since late round 3: with four waves of 128 x 64 (WFM = 4: 512 registers, one
+// wave per SIMD) the matrix pipe was busy 0.65 of a wave's time and nothing ran while the wave waited at the k-tile's
+// barrier or for LDS (profiles/r03_draw_b3_issue_pmc.txt); two waves per SIMD cover each other's waits at a third more
+// fragment reads per MFMA: draw 0.354 -> 0.331 ms, trailing updates -6 %, same bits.
+// Software pipeline inside each wave (measured levers in tools/proto_draw_b3p.hip):
 //   * LDS double buffer of k-tiles of 32; image [plane][8-k chunk][row][16 B] (+32 B per chunk
 //     plane): fragment reads (4 x 16 lanes, 64 banks) and tile writes (8 x 8 lanes over a 128-byte
 //     window) are conflict-free without row padding;
@@ -60,27 +65,32 @@ __device__ __forceinline__ float h2_scale(float bound) {  // 2^e with bound * 2^
   return ldexpf(1.0f, e);
 }
 
-// WFM_ = 4: the 256 x 128 tile described above.  WFM_ = 2: a 128 x 128 tile (wave tiles 64 x 64, 99.8 KB of
-// LDS) for problems with fewer 256-row tiles than CUs — half the MFMAs per k-tile against two thirds of the
-// operand bytes, but twice the workgroups.
+// WFM_ = 2 on four waves: a 128 x 128 tile (99.8 KB of LDS) for problems with fewer 256-row tiles than CUs — half
+// the MFMAs per k-tile against two thirds of the operand bytes, but twice the workgroups.
 // NP_ = 3: three bf16 planes per operand, six piece products (above).  NP_ = 2: "fp16 x 2" — two fp16 planes
 // (11 + 11 significand bits of the operand, which the caller has scaled into fp16's range) and the three
 // products a0 b1, a1 b0, a0 b0 on v_mfma_f32_32x32x16_f16: half the matrix work; the operands are rounded to
 // 22 bits, and the measured error of a K = 4096 product is the same 8e-8 of sum|a b| as bf16 x 3's, because the
 // f32 accumulation dominates both (tools/ub_bf16x3.hip).  Planes are 2-byte elements either way.
-template <int WFM_, int NP_ = 3> struct PipeB3T {
+template <int WFM_, int NP_ = 3, int NW_ = 4> struct PipeB3T {
   static constexpr int WFM = WFM_, WFN = 2;  // 32 x 32 MFMA tiles per wave: (32 WFM) x 64
   static constexpr int NP = NP_;
+  static constexpr int NW = NW_;             // waves per workgroup: 2 along N (64 columns each) x NW / 2 along M
+  static constexpr int NTH = 64 * NW;
   static constexpr int NPROD = NP == 3 ? 6 : 3;
-  static constexpr int TM = 64 * WFM;        // rows of the A operand per workgroup
+  static constexpr int TM = 32 * WFM * (NW / 2);  // rows of the A operand per workgroup
+  static constexpr int RPP = NTH / 4;             // rows one pass of tile loads covers (4 threads per row)
+  static constexpr int PA = TM / RPP, PB = B3_TN / RPP;  // passes per plane
   static constexpr int PAD = 32;
   static constexpr int CPA = TM * 16 + PAD, CPB = B3_TN * 16 + PAD;  // bytes per (plane, chunk)
   static constexpr int A_BYTES = NP * 4 * CPA, STAGE = NP * 4 * (CPA + CPB);
   static constexpr int LDS_BYTES = 2 * STAGE;
-  static constexpr int NQA = NP * WFM, NQB = NP * 2;  // 16-byte vectors per thread and k-tile
+  static constexpr int NQA = NP * PA, NQB = NP * PB;  // 16-byte vectors per thread and k-tile
   static constexpr int NRD = NP * (WFM + WFN);        // fragment reads per k16 step
   static constexpr int NMF = NPROD * WFM * WFN;       // MFMAs per k16 step
   static constexpr int LEAD = (WFM == 4 && NP == 3) ? 6 : 0;
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  static_assert(TM % RPP == 0 && B3_TN % RPP == 0, "whole load passes");
 
   i32x4_t pre[NQA + NQB];
   i32x4_t fa[2][NP][WFM], fb[2][NP][WFN];  // fragments: 8 two-byte elements each
@@ -119,18 +129,18 @@ template <int WFM_, int NP_ = 3> struct PipeB3T {
   __device__ __forceinline__ void gload(int k0) {
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
-      pre[q] = raw_buffer_load_b128(rsA[q / WFM], voffA, (q % WFM) * 64 * lda2 + k0 * 2, 0);
+      pre[q] = raw_buffer_load_b128(rsA[q / PA], voffA, (q % PA) * RPP * lda2 + k0 * 2, 0);
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
-      pre[NQA + q] = raw_buffer_load_b128(rsB[q >> 1], voffB, (q & 1) * 64 * ldb2 + k0 * 2, 0);
+      pre[NQA + q] = raw_buffer_load_b128(rsB[q / PB], voffB, (q % PB) * RPP * ldb2 + k0 * 2, 0);
   }
   template <int BUF> __device__ __forceinline__ void lstore(unsigned char *lds) {
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
-      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_a + (q / WFM) * 4 * CPA + (q % WFM) * 1024) = pre[q];
+      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_a + (q / PA) * 4 * CPA + (q % PA) * RPP * 16) = pre[q];
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
-      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_b + (q >> 1) * 4 * CPB + (q & 1) * 1024) = pre[NQA + q];
+      *reinterpret_cast<i32x4_t *>(lds + BUF * STAGE + wr_b + (q / PB) * 4 * CPB + (q % PB) * RPP * 16) = pre[NQA + q];
   }
   template <int BUF, int S> __device__ __forceinline__ void read_sub(const unsigned char *lds) {
 #pragma unroll

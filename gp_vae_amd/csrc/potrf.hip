@@ -1017,14 +1017,14 @@ struct SyrkB3Map {
 
 // NP = 2: the planes hold L * s (fp16 x 2, b3.hpp); the accumulators start from -C s^2 and are multiplied by
 // 1 / s^2 before the store (powers of two: exact).
-template <int NP, int WFM>
-__global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
+template <int NP, int WFM, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void potrf_syrk_b3_kernel(float *A, int64_t lda,
                                                                     int64_t strideA, B3Out o3,
                                                                     int64_t cP, int K, int64_t kend,
                                                                     SyrkB3Map map) {
   using M = Mfma<float>;
-  using PipeB3 = PipeB3T<WFM, NP>;
-  constexpr int TM = PipeB3::TM;  // 256 (WFM = 4) or 128 (WFM = 2: map.half)
+  using PipeB3 = PipeB3T<WFM, NP, NW>;
+  constexpr int TM = PipeB3::TM;  // 256 (WFM = 4, or WFM = 2 on eight waves) or 128 (WFM = 2 on four: map.half)
   __shared__ __align__(16) unsigned char lds[PipeB3::LDS_BYTES];
   int b, tr, tc;
   if (!map.decode(blockIdx.x, b, tr, tc)) return;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
   float *Ab = A + (int64_t)b * strideA;
   const __bf16 *Pb = o3.p + (int64_t)b * o3.stride + (cP - o3.col0);  // row 0, first column of the K panel columns
   const int64_t r0 = kend + (int64_t)tr * TM, q0 = kend + (int64_t)tc * B3_TN;
-  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (32 * WFM), wn = (wave & 1) * 64;
   PipeB3 P;
   P.init(Pb + r0 * o3.ld, o3.ld, o3.plane, Pb + q0 * o3.ld, o3.ld, o3.plane, tid, wm, wn);
   TileIO<float> io;
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void potrf_syrk_b3_kernel(float *A, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) P.acc[fm][fn][r] *= is2;
   }
-  if (WFM == 4 ? tc < 2 * tr : tc < tr) {  // wholly below the diagonal
+  if (TM == 256 ? tc < 2 * tr : tc < tr) {  // wholly below the diagonal
 #pragma unroll
     for (int fm = 0; fm < PipeB3::WFM; ++fm)
 #pragma unroll
@@ -1293,13 +1293,13 @@ static int run_potrf_v(hipStream_t st, int64_t n, int batch, void *A, int64_t ld
         if (0.53 * (double)cdiv(hmap.grid(), (int64_t)256) < (double)cdiv(map.grid(), (int64_t)256)) map = hmap;
         const int K = (jj + 1) * NBO;
         const dim3 grid((unsigned)map.grid());
-#define GPVAE_SYRK_B3(NPV, WFMV)                                                                              \
-  hipLaunchKernelGGL((potrf_syrk_b3_kernel<NPV, WFMV>), grid, dim3(NTHREADS), 0, st, (float *)A, lda, strideA, o3, cP, \
-                     K, kend, map)
+#define GPVAE_SYRK_B3(NPV, WFMV, NWV)                                                                         \
+  hipLaunchKernelGGL((potrf_syrk_b3_kernel<NPV, WFMV, NWV>), grid, dim3(64 * NWV), 0, st, (float *)A, lda, strideA, o3, \
+                     cP, K, kend, map)
         if (o3.np == 2) {
-          if (map.half) GPVAE_SYRK_B3(2, 2); else GPVAE_SYRK_B3(2, 4);
+          if (map.half) GPVAE_SYRK_B3(2, 2, 4); else GPVAE_SYRK_B3(2, 2, 8);
         } else {
-          if (map.half) GPVAE_SYRK_B3(3, 2); else GPVAE_SYRK_B3(3, 4);
+          if (map.half) GPVAE_SYRK_B3(3, 2, 4); else GPVAE_SYRK_B3(3, 2, 8);
         }
 #undef GPVAE_SYRK_B3
         continue;
