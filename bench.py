@@ -491,7 +491,7 @@ def main():
                 draw_timed, args.steps, DRAW_EVENTS_EVERY)
             roof["note"] = ("avg_launch_ms / frac: HIP events around the draw's launches INSIDE the timed steps, where the "
                             "factor stream's and the normals stream's workgroups hold part of the CUs (a draw workgroup "
-                            "fills a CU's LDS and register file: a CU runs the draw or something else, never both); "
+                            "fills a CU's LDS (145 KB of 160): nothing that needs LDS runs beside it on that CU); "
                             "avg_launch_ms_alone / frac_alone: the same launch with nothing beside it on the chip")
             if draw_alone_ms:  # the kernel's own time (what a kernel trace reports), nothing beside it on the chip
                 roof["avg_launch_ms_alone"] = draw_alone_ms
